@@ -1,0 +1,134 @@
+"""FlashAttention forward/backward for MI355X behind the reference's call surface.
+
+Counterpart of the reference's code/My_FlashAttention_optimized.py: same module name, same
+public names, argument order and defaults --
+
+    flash_attention(Q, K, V, is_causal=False) -> O                       (M:169)
+    FlashAttentionFunction.forward / .backward                           (M:130-166)
+    flash_attention_forward(Q, K, V, is_causal) -> (O, LSE)              (M:14-60)
+    flash_attention_backward(Q, K, V, O, dO, LSE, is_causal) -> (dQ, dK, dV)   (M:62-128)
+    compare_with_sdpa(Q, K, V, is_causal)                                (M:172-212)
+
+-- but the three Triton launches are three calls into libmi355fa.so (hand-written gfx950
+HIP kernels, C ABI in include/mi355fa.h) on PyTorch's current stream.  PyTorch only
+provides device memory, the stream and autograd.  There is no Triton and no fallback: on
+a machine without the built library the import fails.
+"""
+import torch
+import torch.nn.functional as F
+
+import _mi355fa as _fa
+
+_DTYPES = {torch.float16: _fa.FP16, torch.bfloat16: _fa.BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def flash_attention_forward(Q, K, V, is_causal):
+    """Allocate O / LSE and enqueue the forward kernel (M:14-60)."""
+    B, H, S_q, D = Q.shape
+    _, _, S_k, _ = K.shape
+    O = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
+    LSE = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
+    with torch.cuda.device(Q.device):
+        rc = _fa.lib.fa_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), LSE.data_ptr(),
+                            B, H, S_q, S_k, D, _DTYPES[Q.dtype], int(bool(is_causal)),
+                            1 / (D ** 0.5), _stream())
+    _fa.check(rc, "fa_fwd")
+    return O, LSE
+
+
+def flash_attention_backward(Q, K, V, O, dO, LSE, is_causal):
+    """Allocate dQ/dK/dV/delta and enqueue dQ (+delta) then dK/dV (M:62-128)."""
+    B, H, S_q, D = Q.shape
+    _, _, S_k, _ = K.shape
+    dQ = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
+    dK = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
+    dV = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
+    delta = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
+    dt, causal, scale = _DTYPES[Q.dtype], int(bool(is_causal)), 1 / (D ** 0.5)
+    with torch.cuda.device(Q.device):
+        s = _stream()
+        rc = _fa.lib.fa_bwd_dq(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(),
+                               LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
+                               B, H, S_q, S_k, D, dt, causal, scale, s)
+        _fa.check(rc, "fa_bwd_dq")
+        # same stream, after dQ: the dK/dV kernel reads the delta the dQ kernel wrote (K:376)
+        rc = _fa.lib.fa_bwd_dkv(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(),
+                                LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                                B, H, S_q, S_k, D, dt, causal, scale, s)
+        _fa.check(rc, "fa_bwd_dkv")
+    return dQ, dK, dV
+
+
+class FlashAttentionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, K, V, is_causal: bool):
+        assert Q.is_cuda and K.is_cuda and V.is_cuda
+        assert Q.dtype in (torch.float16, torch.bfloat16)
+        assert Q.dtype == K.dtype == V.dtype
+        assert Q.shape[-1] == K.shape[-1] == V.shape[-1]
+        assert Q.ndim == 4 and K.ndim == 4 and V.ndim == 4
+        assert Q.shape[-1] in (64, 128), "head dim must be 64 or 128"
+        Q_ = Q.contiguous()
+        K_ = K.contiguous()
+        V_ = V.contiguous()
+        O, LSE = flash_attention_forward(Q_, K_, V_, is_causal)
+        ctx.save_for_backward(Q_, K_, V_, O, LSE)
+        ctx.is_causal = is_causal
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, K, V, O, LSE = ctx.saved_tensors
+        dO_ = dO.contiguous()
+        dQ, dK, dV = flash_attention_backward(Q, K, V, O, dO_, LSE, ctx.is_causal)
+        return dQ, dK, dV, None
+
+
+def flash_attention(Q, K, V, is_causal=False):
+    return FlashAttentionFunction.apply(Q, K, V, is_causal)
+
+
+def sdpa_reference(Q, K, V, is_causal):
+    """torch SDPA on the device, fp16/bf16 (the reference pins the FLASH backend, M:178;
+    here whatever backend this PyTorch-ROCm build selects)."""
+    return F.scaled_dot_product_attention(Q, K, V, attn_mask=None, dropout_p=0.0, is_causal=is_causal)
+
+
+def compare_with_sdpa(Q, K, V, is_causal, verbose=True):
+    """Fwd+bwd of SDPA and of flash_attention on the same inputs and dO; verifies O, dQ, dK, dV
+    in that order (M:172-212).  Returns the four metric dicts."""
+    Q_ref = Q.detach().clone().requires_grad_(True)
+    K_ref = K.detach().clone().requires_grad_(True)
+    V_ref = V.detach().clone().requires_grad_(True)
+    O_ref = sdpa_reference(Q_ref, K_ref, V_ref, is_causal)
+    dO = torch.randn_like(O_ref)
+    O_ref.backward(dO)
+    dQ_ref, dK_ref, dV_ref = Q_ref.grad, K_ref.grad, V_ref.grad
+
+    Q_ = Q.detach().clone().requires_grad_(True)
+    K_ = K.detach().clone().requires_grad_(True)
+    V_ = V.detach().clone().requires_grad_(True)
+    O = flash_attention(Q_, K_, V_, is_causal=is_causal)
+    O.backward(dO)
+    dQ, dK, dV = Q_.grad, K_.grad, V_.grad
+
+    from _verify_func import verify_results
+    out = {}
+    for name, ref, got in (("O", O_ref, O), ("dQ", dQ_ref, dQ), ("dK", dK_ref, dK), ("dV", dV_ref, dV)):
+        if verbose:
+            print("=" * 30 + " " + name + " test " + "=" * 30)
+        out[name] = verify_results(ref, got, name=name, verbose=verbose)
+    return out
+
+
+if __name__ == "__main__":
+    DEVICE = torch.device(torch.cuda.current_device())
+    B, H, S_q, S_k, D = 4, 8, 256, 256, 64
+    Q = torch.randn((B, H, S_q, D), dtype=torch.float16, device=DEVICE)
+    K = torch.randn((B, H, S_k, D), dtype=torch.float16, device=DEVICE)
+    V = torch.randn((B, H, S_k, D), dtype=torch.float16, device=DEVICE)
+    compare_with_sdpa(Q, K, V, is_causal=True)

@@ -1,0 +1,88 @@
+// C ABI of libmi355fa.so (declared in include/mi355fa.h): argument checks, then enqueue.
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mi355fa.h"
+#include "fa_kernels.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* fmt, const char* what) {
+  snprintf(g_err, sizeof(g_err), fmt, what);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+  return (int)e;
+}
+
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+int check_common(const char* fn, int B, int H, int Sq, int Sk, int D, int dtype) {
+  if (B < 1 || H < 1 || Sq < 1 || Sk < 1) return fail(MI355FA_ERR_SHAPE, "%s: B, H, S_q, S_k must be >= 1", fn);
+  if (D != 64 && D != 128) return fail(MI355FA_ERR_HEAD_DIM, "%s: head dim must be 64 or 128", fn);
+  if (dtype != MI355FA_FP16 && dtype != MI355FA_BF16) return fail(MI355FA_ERR_DTYPE, "%s: dtype must be 0 (fp16) or 1 (bf16)", fn);
+  // one (batch, head) slice is addressed with 32-bit buffer offsets
+  const long long lim = (1ll << 31) - 1;
+  if ((long long)Sq * D * 2 > lim || (long long)Sk * D * 2 > lim)
+    return fail(MI355FA_ERR_SHAPE, "%s: one (batch, head) slice exceeds 2^31 bytes", fn);
+  if ((long long)B * H * ((Sq > Sk ? Sq : Sk) + 127) / 128 > lim)
+    return fail(MI355FA_ERR_SHAPE, "%s: too many tiles for one launch", fn);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fa_abi_version(void) { return MI355FA_ABI_VERSION; }
+
+const char* fa_last_error(void) { return g_err; }
+
+int fa_supported(int D, int dtype) {
+  return (D == 64 || D == 128) && (dtype == MI355FA_FP16 || dtype == MI355FA_BF16);
+}
+
+int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+           int dtype, int causal, float scale, void* stream) {
+  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd");
+  if (int rc = check_common("fa_fwd", B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd");
+  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0};
+  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_fwd launch");
+  return 0;
+}
+
+int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+              float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq");
+  if (int rc = check_common("fa_bwd_dq", B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
+      misaligned(dq) || misaligned(delta))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq");
+  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0};
+  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
+  return 0;
+}
+
+int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+               void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+               void* stream) {
+  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv");
+  if (int rc = check_common("fa_bwd_dkv", B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
+      misaligned(dk) || misaligned(dv))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv");
+  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0};
+  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
+  return 0;
+}
+
+}  // extern "C"

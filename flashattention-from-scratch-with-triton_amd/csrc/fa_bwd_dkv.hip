@@ -1,0 +1,260 @@
+// FlashAttention backward, key-tile-stationary half: dK and dV.
+//
+// Replaces the reference's flash_attention_dKV_kernel
+// (code/_flash_attention_kernel_optimized.py:292-386).  Semantics kept: runs AFTER the dQ
+// kernel and loads the delta it stored (K:376, launch order M:111-126); P recomputed from
+// LSE (K:367); P^T and dS^T rounded to the input dtype before their matmuls (K:370, K:382);
+// padded query rows contribute nothing (K:355-356); causal loop starts at the key tile
+// (K:341); dK, dV cast on store (K:385-386).  (scale applied once to the fp32 dK.)
+//
+// Decomposition: workgroup = 4 waves = 128 keys of one (batch, head); wave = 32 keys whose
+// K and V fragments stay in registers as MFMA B operands, and whose dK^T / dV^T tiles
+// ([d][key], key on the lane) stay in fp32 accumulators for the whole kernel -- no
+// cross-workgroup reduction.  Q and dO stream through LDS in 64-row tiles (one swizzled
+// image each, read by rows for S / dP and transposed for dV^T / dK^T), with
+// -LSE*log2(e) and -delta staged beside them.  With the key on the lane,
+//     S  = Q K^T             (A = Q rows,  B = K^T resident)
+//     dP = dO V^T - delta    (A = dO rows, B = V^T resident; -delta[q] preloaded as C)
+// have the query index in the accumulator REGISTER, so P and dS = P o dP are, after
+// rounding, directly the B operands of dV^T += dO^T P and dK^T += Q^T dS.
+#include <type_traits>
+
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <int D>
+struct DkvCfg {
+  static constexpr int BK = 128;  // keys per workgroup
+  static constexpr int BQ = 64;   // query rows per LDS tile
+  static constexpr int NT = 256;
+  static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
+  static constexpr int TILE_BYTES = BQ * ROWB;
+  static constexpr int STAGE = (BQ * CPR) / NT;
+  static constexpr int ROWC_OFF = 4 * TILE_BYTES;           // row constants after Q[2], dO[2]
+  static constexpr int ROWC_BYTES = 2 * BQ * 4;             // nl[64], nd[64] per buffer
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES + 2 * ROWC_BYTES;
+};
+
+template <int D, typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdParams p) {
+  using C = DkvCfg<D>;
+  using vec8 = typename T::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FA_LDS char* smem = (FA_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = w / p.n_tiles;
+  const int kt_idx = w - bh * p.n_tiles;  // causal: low key tiles are the heavy ones and come first
+  const int k0_wg = kt_idx * C::BK;
+  const int kw0 = k0_wg + wave * 32;
+
+  const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + qoff, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+
+  // ---- resident B operands: K^T and V^T of this wave's 32 keys ----
+  vec8 kf[C::KS], vf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int off = (kw0 + r) * C::ROWB + (2 * ks + h) * 16;
+    kf[ks] = as_vec8<T>(buf_load16(rk, off));
+    vf[ks] = as_vec8<T>(buf_load16(rv, off));
+  }
+
+  const int ntiles = (p.Sq + C::BQ - 1) / C::BQ;
+  const int t_start = CAUSAL ? k0_wg / C::BQ : 0;
+  // tiles t >= t_full are entirely below the diagonal for this wave's keys
+  const int t_full = CAUSAL ? kw0 / C::BQ + 1 : 0;
+
+  int st_g[C::STAGE], st_l[C::STAGE];
+#pragma unroll
+  for (int i = 0; i < C::STAGE; ++i) {
+    const int id = tid + C::NT * i, row = id / C::CPR, c = id % C::CPR;
+    st_g[i] = row * C::ROWB + c * 16;
+    st_l[i] = lds_off<D>(row, c);
+  }
+  int row_off[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
+  int tr_off[2][C::DB];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
+
+  const float c2 = p.scale * kLog2e;
+  f32x16 dkacc[C::DB], dvacc[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dkacc[db][i] = 0.f;
+      dvacc[db][i] = 0.f;
+    }
+
+  u32x4 qst[C::STAGE], dst[C::STAGE];
+  float cst = 0.f;  // threads 0..63: LSE row, 64..127: delta row
+  auto stage_load = [&](int t) {
+    const int base = t * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::STAGE; ++i) {
+      qst[i] = buf_load16(rq, base + st_g[i]);
+      dst[i] = buf_load16(rdo, base + st_g[i]);
+    }
+    if (tid < 64) {
+      cst = buf_load_f32(rl, (t * C::BQ + tid) * 4);
+    } else if (tid < 128) {
+      cst = buf_load_f32(rd, (t * C::BQ + tid - 64) * 4);
+    }
+  };
+  auto stage_write = [&](int t) {
+    const int buf = t & 1;
+    FA_LDS char* qd = smem + buf * C::TILE_BYTES;
+    FA_LDS char* dd = smem + (2 + buf) * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::STAGE; ++i) {
+      lds_write16(qd + st_l[i], qst[i]);
+      lds_write16(dd + st_l[i], dst[i]);
+    }
+    FA_LDS float* rc = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
+    if (tid < 64) {
+      // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
+      rc[tid] = (t * C::BQ + tid < p.Sq) ? -cst * kLog2e : -INFINITY;
+    } else if (tid < 128) {
+      rc[tid] = -cst;  // rc[64 + row] = -delta
+    }
+  };
+
+  auto tile = [&](int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int buf = t & 1;
+    const FA_LDS char* qt = smem + buf * C::TILE_BYTES;
+    const FA_LDS char* dt = smem + (2 + buf) * C::TILE_BYTES;
+    const FA_LDS char* rc = smem + C::ROWC_OFF + buf * C::ROWC_BYTES;
+    const int q0 = t * C::BQ;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int qb0 = q0 + 32 * b;
+      if constexpr (MASKED) {
+        if (qb0 < kw0) continue;  // every row of the block is above the diagonal
+      }
+      const FA_LDS char* qbp = qt + b * 32 * C::ROWB;
+      const FA_LDS char* dbp = dt + b * 32 * C::ROWB;
+      // per-register row constants: reg i <-> row (i&3) + 8(i>>2) + 4h
+      f32x16 nl, pacc, sacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a = *(const FA_LDS f32x4*)(rc + (32 * b + 8 * g + 4 * h) * 4);
+        const f32x4 d = *(const FA_LDS f32x4*)(rc + (64 + 32 * b + 8 * g + 4 * h) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          nl[4 * g + j] = a[j];
+          pacc[4 * g + j] = d[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
+        sacc = T::mfma(a, kf[ks], sacc);
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(dbp + row_off[ks]));
+        pacc = T::mfma(a, vf[ks], pacc);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float x = __builtin_fmaf(sacc[i], c2, nl[i]);
+        if constexpr (MASKED) {
+          const int qrow = qb0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          x = (kw0 + r > qrow) ? -INFINITY : x;
+        }
+        const float pe = __builtin_amdgcn_exp2f(x);
+        sacc[i] = pe;             // P
+        pacc[i] = pe * pacc[i];   // dS = P o (dP - delta)
+      }
+      const vec8 p0 = pack8<T, 0>(sacc), p1 = pack8<T, 1>(sacc);
+      const vec8 s0 = pack8<T, 0>(pacc), s1 = pack8<T, 1>(pacc);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        vec8 a0 = lds_read_tr_frag<T>(dbp + tr_off[0][db], dbp + tr_off[1][db]);
+        dvacc[db] = T::mfma(a0, p0, dvacc[db]);
+        vec8 a1 = lds_read_tr_frag<T>(dbp + 16 * C::ROWB + tr_off[0][db], dbp + 16 * C::ROWB + tr_off[1][db]);
+        dvacc[db] = T::mfma(a1, p1, dvacc[db]);
+      }
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        vec8 a0 = lds_read_tr_frag<T>(qbp + tr_off[0][db], qbp + tr_off[1][db]);
+        dkacc[db] = T::mfma(a0, s0, dkacc[db]);
+        vec8 a1 = lds_read_tr_frag<T>(qbp + 16 * C::ROWB + tr_off[0][db], qbp + 16 * C::ROWB + tr_off[1][db]);
+        dkacc[db] = T::mfma(a1, s1, dkacc[db]);
+      }
+    }
+  };
+
+  if (t_start < ntiles) {
+    stage_load(t_start);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tile + K/V fragments landed
+    stage_write(t_start);
+  }
+  __syncthreads();
+  int t = t_start;
+  const int t_masked_end = min(ntiles, t_full);
+  for (; t < t_masked_end; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    tile(t, std::true_type{});
+    if (more) stage_write(t + 1);
+    __syncthreads();
+  }
+  for (; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    tile(t, std::false_type{});
+    if (more) stage_write(t + 1);
+    __syncthreads();
+  }
+
+  FA_LDS char* stage = smem + wave * 32 * C::ROWB;
+  store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * C::ROWB, lane);
+  store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * C::ROWB, lane);
+}
+
+template <int D, typename T, bool CAUSAL>
+static hipError_t launch(const BwdParams& p, hipStream_t s) {
+  using C = DkvCfg<D>;
+  const int grid = p.n_tiles * p.B * p.H;
+  auto kern = fa_bwd_dkv_kernel<D, T, CAUSAL>;
+  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  p.n_tiles = (p.Sk + 127) / 128;
+#define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
+  if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
+  if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
+#undef FA_GO
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fa

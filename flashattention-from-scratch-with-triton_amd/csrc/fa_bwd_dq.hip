@@ -1,0 +1,224 @@
+// FlashAttention backward, query-tile-stationary half: dQ and delta = rowsum(dO * O).
+//
+// Replaces the reference's flash_attention_dQ_kernel
+// (code/_flash_attention_kernel_optimized.py:165-258).  Semantics kept: delta from the
+// ROUNDED 16-bit O in fp32 (K:210-211) and stored for the dK/dV kernel (K:258);
+// P recomputed from the forward's LSE (K:244); dS rounded to the input dtype before
+// dS @ K (K:253); dQ cast on store (K:256).  (scale is applied once to the fp32
+// accumulator instead of to every partial product.)
+//
+// Decomposition: workgroup = 4 waves = 128 query rows, wave = 32 rows; K and V stream
+// through LDS in 64-key tiles exactly as in the forward.  Both score-shaped products are
+// computed transposed with the query on the lane,
+//     S^T  = K Q^T          (A = K rows from LDS,  B = Q^T  resident in registers)
+//     dP^T = V dO^T - delta (A = V rows from LDS,  B = dO^T resident; -delta[q] is the
+//                            accumulator's initial value: q is the lane, so it is one
+//                            broadcast register tuple and costs no VALU per tile)
+// so LSE / delta are per-lane scalars and dS^T = P^T o dP^T, rounded, is directly the
+// B operand of dQ^T += K^T dS^T (K^T fetched from the same LDS image by
+// ds_read_b64_tr_b16).
+#include <type_traits>
+
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <int D>
+struct DqCfg {
+  static constexpr int BM = 128, BN = 64, NT = 256;
+  static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
+  static constexpr int TILE_BYTES = BN * ROWB;
+  static constexpr int STAGE = (BN * CPR) / NT;
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;
+};
+
+template <int D, typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dq_kernel(BwdParams p) {
+  using C = DqCfg<D>;
+  using vec8 = typename T::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FA_LDS char* smem = (FA_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = w / p.n_tiles;
+  int qt = w - bh * p.n_tiles;
+  if (CAUSAL) qt = p.n_tiles - 1 - qt;
+  const int q0_wg = qt * C::BM;
+  const int qw0 = q0_wg + wave * 32;
+
+  const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + qoff, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)p.o + qoff, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + qoff, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+
+  // ---- resident B operands: Q^T and dO^T of this wave's 32 rows; delta ----
+  vec8 qf[C::KS], dof[C::KS];
+  float dsum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int off = (qw0 + r) * C::ROWB + (2 * ks + h) * 16;
+    qf[ks] = as_vec8<T>(buf_load16(rq, off));
+    dof[ks] = as_vec8<T>(buf_load16(rdo, off));
+    const vec8 of = as_vec8<T>(buf_load16(ro, off));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum = __builtin_fmaf((float)dof[ks][j], (float)of[j], dsum);
+  }
+  const float delta = half_sum(dsum);
+  const float nl = -buf_load_f32(rl, (qw0 + r) * 4) * kLog2e;
+  if (h == 0) buf_store_f32(rd, (qw0 + r) * 4, delta);
+  f32x16 ndelta;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ndelta[i] = -delta;
+
+  const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
+  const int ntiles = (kv_end + C::BN - 1) / C::BN;
+  const int nfull = CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN;
+
+  int st_g[C::STAGE], st_l[C::STAGE];
+#pragma unroll
+  for (int i = 0; i < C::STAGE; ++i) {
+    const int id = tid + C::NT * i, row = id / C::CPR, c = id % C::CPR;
+    st_g[i] = row * C::ROWB + c * 16;
+    st_l[i] = lds_off<D>(row, c);
+  }
+  int row_off[C::KS];  // A-operand row reads (K rows and V rows)
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
+  int tr_off[2][C::DB];  // transposed reads of K
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
+
+  const float c2 = p.scale * kLog2e;
+  f32x16 dqacc[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqacc[db][i] = 0.f;
+
+  u32x4 kst[C::STAGE], vst[C::STAGE];
+  auto stage_load = [&](int t) {
+    const int base = t * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::STAGE; ++i) {
+      kst[i] = buf_load16(rk, base + st_g[i]);
+      vst[i] = buf_load16(rv, base + st_g[i]);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    FA_LDS char* kd = smem + buf * C::TILE_BYTES;
+    FA_LDS char* vd = smem + (2 + buf) * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::STAGE; ++i) {
+      lds_write16(kd + st_l[i], kst[i]);
+      lds_write16(vd + st_l[i], vst[i]);
+    }
+  };
+
+  auto tile = [&](int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
+    const int s0 = t * C::BN;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if constexpr (MASKED) {
+        bool use = s0 + 32 * b < p.Sk;
+        if (CAUSAL) use = use && (s0 + 32 * b <= qw0);
+        if (!use) continue;
+      }
+      const FA_LDS char* kbp = kt + b * 32 * C::ROWB;
+      const FA_LDS char* vbp = vt + b * 32 * C::ROWB;
+      f32x16 sacc, pacc = ndelta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(kbp + row_off[ks]));
+        sacc = T::mfma(a, qf[ks], sacc);
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(vbp + row_off[ks]));
+        pacc = T::mfma(a, dof[ks], pacc);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float x = __builtin_fmaf(sacc[i], c2, nl);
+        if constexpr (MASKED) {
+          const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool dead = (CAUSAL && key > qw0 + r) || key >= p.Sk;
+          x = dead ? -INFINITY : x;
+        }
+        sacc[i] = __builtin_amdgcn_exp2f(x) * pacc[i];  // dS^T = P^T o (dP^T - delta)
+      }
+      const vec8 d0 = pack8<T, 0>(sacc);
+      const vec8 d1 = pack8<T, 1>(sacc);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        vec8 a0 = lds_read_tr_frag<T>(kbp + tr_off[0][db], kbp + tr_off[1][db]);
+        dqacc[db] = T::mfma(a0, d0, dqacc[db]);
+        vec8 a1 = lds_read_tr_frag<T>(kbp + 16 * C::ROWB + tr_off[0][db], kbp + 16 * C::ROWB + tr_off[1][db]);
+        dqacc[db] = T::mfma(a1, d1, dqacc[db]);
+      }
+    }
+  };
+
+  stage_load(0);
+  stage_write(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  int t = 0;
+  for (; t < nfull; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    tile(t, std::false_type{});
+    if (more) stage_write((t + 1) & 1);
+    __syncthreads();
+  }
+  for (; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    tile(t, std::true_type{});
+    if (more) stage_write((t + 1) & 1);
+    __syncthreads();
+  }
+
+  store_tile_rows<D, T>(dqacc, p.scale, smem + wave * 32 * C::ROWB, rdq, qw0 * C::ROWB, lane);
+}
+
+template <int D, typename T, bool CAUSAL>
+static hipError_t launch(const BwdParams& p, hipStream_t s) {
+  using C = DqCfg<D>;
+  const int grid = p.n_tiles * p.B * p.H;
+  auto kern = fa_bwd_dq_kernel<D, T, CAUSAL>;
+  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  p.n_tiles = (p.Sq + 127) / 128;
+#define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
+  if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
+  if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
+#undef FA_GO
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fa

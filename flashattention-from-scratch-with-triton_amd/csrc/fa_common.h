@@ -1,0 +1,199 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) FlashAttention kernels.
+//
+// Everything here is written for wave64 + v_mfma_f32_32x32x16_{bf16,f16} only.
+//
+// Fragment conventions used by all three kernels (lane l: r = l & 31, h = l >> 5):
+//   * MFMA A operand (32 rows x 16 k):  lane holds A[row r][k = 8h + j], j = 0..7
+//   * MFMA B operand (16 k x 32 cols):  lane holds B[k = 8h + j][col r], j = 0..7
+//   * MFMA C/D (32 x 32 fp32, 16 regs): reg i of lane = D[row (i&3) + 8(i>>2) + 4h][col r]
+//   * "accumulator as next B operand": regs 8s..8s+7 of a C/D tile, rounded to
+//     16 bit, are the B fragment of k-step s of a product that sums over the
+//     tile's ROW index; element j then stands for row 16s + 8(j>>2) + 4h + (j&3),
+//     and the A operand of that product is fetched in the same k order by two
+//     ds_read_b64_tr_b16 (rows 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3}).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(8))) short i16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+#define FA_LDS __attribute__((address_space(3)))
+#define FA_DEVINL __device__ __forceinline__
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ---- dtype traits ---------------------------------------------------------
+struct BF16 {
+  typedef bf16x8 vec8;
+  typedef __bf16 elem;
+  static FA_DEVINL f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct FP16 {
+  typedef f16x8 vec8;
+  typedef _Float16 elem;
+  static FA_DEVINL f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+FA_DEVINL typename T::vec8 as_vec8(u32x4 v) {
+  return __builtin_bit_cast(typename T::vec8, v);
+}
+
+// regs 8s..8s+7 of a 32x32 fp32 tile -> one 16-bit B fragment (round to nearest even).
+template <typename T, int S>
+FA_DEVINL typename T::vec8 pack8(const f32x16& x) {
+  typename T::vec8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (typename T::elem)x[8 * S + j];
+  return o;
+}
+
+// ---- LDS image ------------------------------------------------------------
+// A tile is [rows][D] 16-bit elements, row stride D*2 bytes, stored in 16-byte
+// chunks whose index is XOR-swizzled with the row so that BOTH the ds_read_b128
+// row reads of an A/B operand (16-lane groups reading 16 different rows at one
+// chunk) and the ds_read_b64_tr_b16 transposed reads (a 32-lane half reading
+// 4 consecutive rows x 64 B) are bank-conflict free (banks = (addr/4) % 64).
+//   D = 64  (128-B rows, two rows per 256-B bank window):
+//       chunk ^= (bit1(row) << 2) | (bit3(row) << 1) | bit2(row)
+//   D = 128 (256-B rows): chunk ^= ((row & 3) << 2) | ((row >> 2) & 3)
+template <int D>
+FA_DEVINL int swz_chunk(int row, int chunk) {
+  if constexpr (D == 64) {
+    return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+  } else {
+    static_assert(D == 128, "head dim must be 64 or 128");
+    return chunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
+  }
+}
+template <int D>
+FA_DEVINL int lds_off(int row, int chunk) {
+  return row * (D * 2) + swz_chunk<D>(row, chunk) * 16;
+}
+
+FA_DEVINL u32x4 lds_read16(const FA_LDS char* p) { return *(const FA_LDS u32x4*)p; }
+FA_DEVINL void lds_write16(FA_LDS char* p, u32x4 v) { *(FA_LDS u32x4*)p = v; }
+FA_DEVINL void lds_write8(FA_LDS char* p, u32x2 v) { *(FA_LDS u32x2*)p = v; }
+
+// ds_read_b64_tr_b16: needs EXEC all ones and an 8-byte aligned address per lane.
+FA_DEVINL i16x4 lds_read_tr(const FA_LDS char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS i16x4*)p);
+}
+
+// A-operand fragment fetched TRANSPOSED from a row-major [row][D] image: result
+// lane (r, h) element j = tile[row0 + 8(j>>2) + 4h + (j&3)][col0 + r].
+// `a0` / `a1` are this lane's byte addresses for the two 4-row blocks (see tr_lane_off).
+template <typename T>
+FA_DEVINL typename T::vec8 lds_read_tr_frag(const FA_LDS char* a0, const FA_LDS char* a1) {
+  i16x4 lo = lds_read_tr(a0);
+  i16x4 hi = lds_read_tr(a1);
+  i16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename T::vec8, v);
+}
+
+// Byte offset this lane supplies to ds_read_b64_tr_b16 for the 4-row block whose first
+// row is `row0 + 4h` (row0 a multiple of 8) and whose 32 columns start at col32*32.
+// Lane l: 16-lane group g = l >> 4 (h = g >> 1 picks rows, g & 1 picks the 16-column
+// half), i = l & 15 -> row i >> 2, columns 4(i & 3) .. 4(i & 3) + 3.
+template <int D>
+FA_DEVINL int tr_lane_off(int lane, int row0, int col32) {
+  const int g = lane >> 4, i = lane & 15;
+  const int row = row0 + 4 * (g >> 1) + (i >> 2);
+  const int p = i & 3;
+  const int chunk = col32 * 4 + (g & 1) * 2 + (p >> 1);
+  return lds_off<D>(row, chunk) + (p & 1) * 8;
+}
+
+// ---- global memory through buffer descriptors (hardware bounds check) -----
+// Out-of-range loads return 0 and out-of-range stores are dropped, which is what
+// gives ragged sequence lengths their masked tails without any branch.
+FA_DEVINL __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+FA_DEVINL u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+FA_DEVINL float buf_load_f32(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+FA_DEVINL void buf_store16(__amdgpu_buffer_rsrc_t r, int off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+FA_DEVINL void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
+// ---- cross-half exchange (lanes l <-> l + 32) -----------------------------
+FA_DEVINL float other_half(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  // r[0] = {own low half replicated}, r[1] = {own high half replicated}; the value that is
+  // not ours is in r[1] for lanes < 32 and in r[0] for lanes >= 32.
+  unsigned o = (threadIdx.x & 32) ? r[0] : r[1];
+  return __builtin_bit_cast(float, o);
+}
+FA_DEVINL float half_max(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+FA_DEVINL float half_sum(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+// ---- workgroup -> work item, XCD aware ------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
+// Give every XCD one contiguous slice of the work list so that the q/k tiles of one
+// (batch, head) stream their K/V (or Q/dO) through ONE L2.  Bijective for any n.
+FA_DEVINL int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, idx = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+}
+
+// ---- epilogue: a wave's 32 x D transposed accumulator -> row-major global ---
+// acc[db][i] holds OUT[row = lane & 31][col = db*32 + (i&3) + 8(i>>2) + 4h] * mul.
+// The wave stages its tile in its own LDS area (32 rows x D*2 bytes, swizzled) and
+// writes whole rows back with 16-byte stores (8 rows per 1-KiB wave instruction).
+template <int D, typename T>
+FA_DEVINL void store_tile_rows(const f32x16 (&acc)[D / 32], float mul, FA_LDS char* stage,
+                               __amdgpu_buffer_rsrc_t dst, int row0_bytes, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < D / 32; ++db) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef __attribute__((ext_vector_type(4))) typename T::elem e4;
+      e4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (typename T::elem)(acc[db][4 * g + j] * mul);
+      lds_write8(stage + lds_off<D>(r, db * 4 + g) + 8 * h, __builtin_bit_cast(u32x2, v));
+    }
+  }
+  // same wave wrote and reads: only the LDS counter needs to drain (wave-local ordering)
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  constexpr int CPR = D / 8;
+#pragma unroll
+  for (int i = 0; i < (32 * CPR) / 64; ++i) {
+    const int id = lane + 64 * i, row = id / CPR, c = id % CPR;
+    u32x4 v = lds_read16(stage + lds_off<D>(row, c));
+    buf_store16(dst, row0_bytes + row * (D * 2) + c * 16, v);
+  }
+}
+
+}  // namespace fa

@@ -1,0 +1,265 @@
+// FlashAttention forward for gfx950: O = softmax(Q K^T / sqrt(D) [+causal]) V, LSE = logsumexp.
+//
+// Replaces the reference's flash_attention_forward_kernel
+// (code/_flash_attention_kernel_optimized.py:35-129); semantics kept: fp32 scores and
+// softmax state, l sums the un-rounded p (K:111), P is rounded to the input dtype for
+// P@V (K:115), O = o / l cast on store (K:120-123), LSE = m + ln(l) (K:126),
+// top-left aligned causal mask (K:102), keys >= S_k masked (K:94).
+//
+// Work decomposition (CDNA4-first, not the reference's 64x64 Triton tiles):
+//   workgroup = 4 waves = 128 query rows of one (batch, head); wave = 32 query rows.
+//   K/V stream through LDS in 64-key tiles (double buffered, swizzled image, one
+//   barrier per tile).  Scores are computed TRANSPOSED, S^T = K Q^T, so the query
+//   index sits on the MFMA lane: the online-softmax row max / row sum are in-lane
+//   reductions plus one lane<->lane+32 exchange, the rescale is a per-lane scalar,
+//   and the fp32 P^T accumulator is, after rounding, directly the B operand of
+//   O^T += V^T P^T (V^T fetched with ds_read_b64_tr_b16) -- P never touches LDS.
+#include <type_traits>
+
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <int D>
+struct FwdCfg {
+  static constexpr int BM = 128;           // query rows per workgroup
+  static constexpr int BN = 64;            // keys per LDS tile
+  static constexpr int NT = 256;           // threads
+  static constexpr int ROWB = D * 2;       // bytes per row
+  static constexpr int CPR = D / 8;        // 16-byte chunks per row
+  static constexpr int KS = D / 16;        // k-steps of S^T = K Q^T
+  static constexpr int DB = D / 32;        // 32-wide d blocks of O^T
+  static constexpr int TILE_BYTES = BN * ROWB;
+  static constexpr int STAGE = (BN * CPR) / NT;  // 16-byte chunks per thread per matrix
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2], V[2]
+};
+
+template <int D, typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParams p) {
+  using C = FwdCfg<D>;
+  using vec8 = typename T::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FA_LDS char* smem = (FA_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- which (batch*head, q tile) ----
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = w / p.nq_tiles;
+  int qt = w - bh * p.nq_tiles;
+  if (CAUSAL) qt = p.nq_tiles - 1 - qt;  // heaviest tiles first
+  const int q0_wg = qt * C::BM;
+  const int qw0 = q0_wg + wave * 32;
+
+  const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
+  const char* kb = (const char*)p.k + (size_t)bh * p.Sk * C::ROWB;
+  const char* vb = (const char*)p.v + (size_t)bh * p.Sk * C::ROWB;
+  char* ob = (char*)p.o + (size_t)bh * p.Sq * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+
+  // ---- Q^T fragments (B operand), resident for the whole kernel ----
+  vec8 qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks)
+    qf[ks] = as_vec8<T>(buf_load16(rq, (qw0 + r) * C::ROWB + (2 * ks + h) * 16));
+
+  // ---- tile schedule ----
+  const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
+  const int ntiles = (kv_end + C::BN - 1) / C::BN;
+  // tiles [0, nfull) need no mask for this wave
+  const int nfull = CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN;
+
+  // ---- staging addresses ----
+  int st_g[C::STAGE], st_l[C::STAGE];
+#pragma unroll
+  for (int i = 0; i < C::STAGE; ++i) {
+    const int id = tid + C::NT * i, row = id / C::CPR, c = id % C::CPR;
+    st_g[i] = row * C::ROWB + c * 16;
+    st_l[i] = lds_off<D>(row, c);
+  }
+  // ---- fragment read addresses (loop invariant) ----
+  int k_off[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) k_off[ks] = lds_off<D>(r, 2 * ks + h);
+  int v_off[2][C::DB];  // [e][dblk]; key-block kb and k-step s add (32*kb + 16*s) rows
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) v_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
+
+  const float c2 = p.scale * kLog2e;  // exp(x*scale) = exp2(x*c2)
+  float m = -INFINITY;                // running row max of the RAW scores (before scale)
+  float l = 0.f;                      // this lane's partial row sum (its 16 of every 32 keys)
+  f32x16 oacc[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+
+  u32x4 kst[C::STAGE], vst[C::STAGE];
+  auto stage_load = [&](int t) {
+    const int base = t * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::STAGE; ++i) {
+      kst[i] = buf_load16(rk, base + st_g[i]);
+      vst[i] = buf_load16(rv, base + st_g[i]);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    FA_LDS char* kd = smem + buf * C::TILE_BYTES;
+    FA_LDS char* vd = smem + (2 + buf) * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::STAGE; ++i) {
+      lds_write16(kd + st_l[i], kst[i]);
+      lds_write16(vd + st_l[i], vst[i]);
+    }
+  };
+
+  // One 64-key tile for this wave.  MASKED = false: every key visible to every row.
+  auto tile = [&](int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
+    const int s0 = t * C::BN;
+    bool use[2] = {true, true};
+    if constexpr (MASKED) {
+      if (CAUSAL) {
+        use[0] = s0 <= qw0;        // key block start <= first row of the wave
+        use[1] = s0 + 32 <= qw0;
+      }
+      use[0] = use[0] && s0 < p.Sk;
+      use[1] = use[1] && s0 + 32 < p.Sk;
+      if (!use[0] && !use[1]) return;
+    }
+    f32x16 sacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (MASKED && !use[b]) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[b][i] = -INFINITY;
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[b][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
+        sacc[b] = T::mfma(a, qf[ks], sacc[b]);
+      }
+      if constexpr (MASKED) {
+        const int qrow = qw0 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool dead = (CAUSAL && key > qrow) || key >= p.Sk;
+          sacc[b][i] = dead ? -INFINITY : sacc[b][i];
+        }
+      }
+    }
+    // ---- online softmax (query on the lane) ----
+    float tm = sacc[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tm = __builtin_fmaxf(tm, sacc[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tm = __builtin_fmaxf(tm, sacc[1][i]);
+    tm = half_max(tm);
+    if (__builtin_amdgcn_ballot_w64(tm > m) != 0) {  // wave-uniform: some row's max grew
+      const float mn = __builtin_fmaxf(m, tm);
+      const float corr = __builtin_amdgcn_exp2f((m - mn) * c2);  // m = -inf -> 0
+      l *= corr;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] *= corr;
+      m = mn;
+    }
+    const float mc = m * c2;
+    float ls = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][i], c2, -mc));
+        sacc[b][i] = pe;
+        ls += pe;
+      }
+    l += ls;
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (MASKED && !use[b]) continue;
+      const vec8 pf0 = pack8<T, 0>(sacc[b]);
+      const vec8 pf1 = pack8<T, 1>(sacc[b]);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        const FA_LDS char* base = vt + b * 32 * C::ROWB;
+        vec8 a0 = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
+        oacc[db] = T::mfma(a0, pf0, oacc[db]);
+        vec8 a1 = lds_read_tr_frag<T>(base + 16 * C::ROWB + v_off[0][db], base + 16 * C::ROWB + v_off[1][db]);
+        oacc[db] = T::mfma(a1, pf1, oacc[db]);
+      }
+    }
+  };
+
+  // ---- main loop: one barrier per tile; every wave runs exactly ntiles iterations ----
+  // (two loops so the unmasked body has no control-flow merge with the masked one)
+  stage_load(0);
+  stage_write(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q fragments landed, nothing pending enters the loop
+  __syncthreads();
+  int t = 0;
+  for (; t < nfull; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    tile(t, std::false_type{});
+    if (more) stage_write((t + 1) & 1);
+    __syncthreads();
+  }
+  for (; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    tile(t, std::true_type{});
+    if (more) stage_write((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float lt = half_sum(l);
+  const float inv = 1.0f / lt;
+  // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
+  store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * C::ROWB, lane);
+  if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * p.scale + __builtin_logf(lt));
+}
+
+// ---- host launcher ----------------------------------------------------------
+template <int D, typename T, bool CAUSAL>
+static hipError_t launch(const FwdParams& p, hipStream_t s) {
+  using C = FwdCfg<D>;
+  const int grid = p.nq_tiles * p.B * p.H;
+  auto kern = fa_fwd_kernel<D, T, CAUSAL>;
+  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  p.nq_tiles = (p.Sq + 127) / 128;
+#define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
+  if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
+  if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
+#undef FA_GO
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fa

@@ -1,0 +1,81 @@
+/* mi355fa.h -- C ABI of libmi355fa.so: FlashAttention forward + backward for MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of
+ * Pearbiossom-M/FlashAttention-from-Scratch-with-Triton.  Each entry point replaces one
+ * Triton kernel launch of the reference's Python launchers (file:line are relative to the
+ * reference repository):
+ *
+ *   fa_fwd      <- flash_attention_forward_kernel launch, code/My_FlashAttention_optimized.py:53-59
+ *                  (kernel code/_flash_attention_kernel_optimized.py:35-129)
+ *   fa_bwd_dq   <- flash_attention_dQ_kernel launch,      code/My_FlashAttention_optimized.py:111-117
+ *                  (kernel code/_flash_attention_kernel_optimized.py:165-258; also writes delta)
+ *   fa_bwd_dkv  <- flash_attention_dKV_kernel launch,     code/My_FlashAttention_optimized.py:120-126
+ *                  (kernel code/_flash_attention_kernel_optimized.py:292-386; reads delta)
+ *
+ * Contract (same as the reference's launchers, M:14-128):
+ *   - every pointer is a DEVICE pointer to a contiguous row-major buffer, 16-byte aligned:
+ *       q, o, dout, dq : [B, H, S_q, D]   16-bit (fp16 or bf16)
+ *       k, v, dk, dv   : [B, H, S_k, D]   16-bit
+ *       lse, delta     : [B, H, S_q]      fp32
+ *   - the CALLER allocates every output; the kernels write every element of o, lse, dq,
+ *     delta, dk, dv (no zero-init needed, nothing is accumulated into);
+ *   - launches are enqueued on `stream` (a hipStream_t; NULL = the default stream) and
+ *     never synchronise; the library allocates nothing and keeps no pointers;
+ *   - fa_bwd_dkv must be enqueued after fa_bwd_dq on the same stream (it reads delta);
+ *   - scale is the softmax scale (the reference always passes 1/sqrt(D));
+ *   - causal != 0 applies the top-left aligned mask  key <= query  (K:102);
+ *   - any S_q, S_k >= 1 is accepted (tails are masked); D must be 64 or 128.
+ *
+ * Every function returns 0 on success.  A negative value is an argument error detected
+ * before anything is launched, a positive value is the hipError_t of the failed launch;
+ * fa_last_error() then returns a thread-local, human-readable description.
+ */
+#ifndef MI355FA_H_
+#define MI355FA_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355FA_ABI_VERSION 1
+
+/* dtype codes */
+#define MI355FA_FP16 0
+#define MI355FA_BF16 1
+
+/* argument errors (negative return values) */
+#define MI355FA_ERR_NULL (-1)      /* a required pointer is NULL */
+#define MI355FA_ERR_SHAPE (-2)     /* B, H, S_q or S_k < 1, or a slice exceeds 2^31 bytes */
+#define MI355FA_ERR_HEAD_DIM (-3)  /* D not in {64, 128} */
+#define MI355FA_ERR_DTYPE (-4)     /* dtype not MI355FA_FP16 / MI355FA_BF16 */
+#define MI355FA_ERR_ALIGN (-5)     /* a pointer is not 16-byte aligned */
+
+int fa_abi_version(void);
+
+/* Thread-local message for the last non-zero return on this thread ("" if none). */
+const char* fa_last_error(void);
+
+/* 1 if (D, dtype) has a kernel, else 0. */
+int fa_supported(int D, int dtype);
+
+/* O = softmax(Q K^T * scale [+causal]) V ; LSE = logsumexp of the scaled, masked scores. */
+int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+           int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+           void* stream);
+
+/* dQ, and delta[b,h,i] = sum_d dO[b,h,i,d] * O[b,h,i,d] (fp32, from the 16-bit O). */
+int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout,
+              const float* lse, void* dq, float* delta,
+              int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+              void* stream);
+
+/* dK and dV; `delta` is the buffer fa_bwd_dq filled. */
+int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout,
+               const float* lse, const float* delta, void* dk, void* dv,
+               int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355FA_H_ */

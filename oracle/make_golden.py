@@ -1,0 +1,100 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Triton kernel bodies on CPU.
+
+TEST INFRASTRUCTURE ONLY (see oracle/fa_oracle.py header).  Run in the build
+container, where /root/reference is mounted; the GPU box never runs this file
+and never sees the reference:
+
+    python oracle/make_golden.py
+
+How (SURVEY.md finding 4): ``TRITON_INTERPRET=1`` executes a ``@triton.jit``
+body with numpy on CPU tensors.  The autotuner wrapper needs a GPU driver, so
+the un-autotuned function is called (``kernel.fn[grid](...)``) with a fixed
+tile config, and the TensorDescriptors get their real ``block_shape`` directly
+(what the pre-hooks K:7-16,134-146,260-273 do).  Launch order and allocations
+follow M:14-128.  fp16 only: the reference kernels hard-cast P/dS to fp16
+(K:115,253,370,382), finding 2.
+
+Only *data* is written: seeded inputs (torch.manual_seed(42), the seed of the
+reference's own tests, Phase_4.md:444,680), and the reference's outputs (the
+fp64 ground truth is recomputed by the tests, it needs no reference).
+"""
+import os
+import sys
+
+os.environ["TRITON_INTERPRET"] = "1"
+REF = "/root/reference/code"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from triton.tools.tensor_descriptor import TensorDescriptor  # noqa: E402
+
+import _flash_attention_kernel_optimized as RK  # noqa: E402  (the reference)
+import fa_oracle  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CASES = [
+    # name, B, H, Sq, Sk, D, causal, BM, BN
+    ("cfg1_b2h4n256d64_noncausal", 2, 4, 256, 256, 64, False, 64, 64),
+    ("cfg1_b2h4n256d64_causal", 2, 4, 256, 256, 64, True, 64, 64),
+    ("cross_b1h2q128k320d64_noncausal", 1, 2, 128, 320, 64, False, 64, 64),
+    ("b1h1n256d128_causal", 1, 1, 256, 256, 128, True, 64, 64),
+    ("b1h2n128d64_causal_bm32bn64", 1, 2, 128, 128, 64, True, 32, 64),
+]
+
+
+def run_reference(Q, K, V, dO, causal, BM, BN):
+    B, H, Sq, D = Q.shape
+    Sk = K.shape[2]
+    scale = 1 / (D ** 0.5)
+
+    def d2(t, rows):
+        return TensorDescriptor(t, shape=[t.numel() // D, D], strides=[D, 1], block_shape=[rows, D], padding="zero")
+
+    def d1(t, rows):
+        return TensorDescriptor(t, shape=[t.numel()], strides=[1], block_shape=[rows], padding="zero")
+
+    O = torch.empty_like(Q)
+    LSE = torch.empty(B, H, Sq, dtype=torch.float32)
+    RK.flash_attention_forward_kernel.fn[(Sq // BM, B * H)](
+        d2(Q, BM), d2(K, BN), d2(V, BN), d2(O, BM), d1(LSE, BM),
+        scale, B, H, Sq, Sk, D, BLOCK_M=BM, BLOCK_N=BN, is_causal=causal)
+    dQ = torch.empty_like(Q)
+    dK = torch.empty_like(K)
+    dV = torch.empty_like(V)
+    delta = torch.empty(B, H, Sq, dtype=torch.float32)
+    RK.flash_attention_dQ_kernel.fn[(Sq // BM, B * H)](
+        d2(Q, BM), d2(K, BN), d2(V, BN), d2(dO, BM), d2(O, BM), d1(LSE, BM), d2(dQ, BM), d1(delta, BM),
+        scale, B, H, Sq, Sk, D, BLOCK_M=BM, BLOCK_N=BN, is_causal=causal)
+    RK.flash_attention_dKV_kernel.fn[(Sk // BN, B * H)](
+        d2(Q, BM), d2(K, BN), d2(V, BN), d2(dO, BM), d1(LSE, BM), d2(dK, BN), d2(dV, BN), d1(delta, BM),
+        scale, B, H, Sq, Sk, D, BLOCK_M=BM, BLOCK_N=BN, is_causal=causal)
+    return dict(O=O, LSE=LSE, delta=delta, dQ=dQ, dK=dK, dV=dV)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, B, H, Sq, Sk, D, causal, BM, BN in CASES:
+        assert Sq % BM == 0 and Sk % BN == 0, "reference descriptor path is only right on whole tiles"
+        torch.manual_seed(42)
+        Q = torch.randn(B, H, Sq, D, dtype=torch.float16)
+        K = torch.randn(B, H, Sk, D, dtype=torch.float16)
+        V = torch.randn(B, H, Sk, D, dtype=torch.float16)
+        dO = torch.randn(B, H, Sq, D, dtype=torch.float16)
+        ref = run_reference(Q, K, V, dO, causal, BM, BN)
+        gt = fa_oracle.attention_fp64(Q, K, V, dO, causal)
+        arrs = dict(Q=Q, K=K, V=V, dO=dO)
+        arrs.update({"ref_" + k: v for k, v in ref.items()})
+        arrs = {k: v.numpy() for k, v in arrs.items()}
+        arrs["meta"] = np.array([B, H, Sq, Sk, D, int(causal), BM, BN], dtype=np.int64)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+        errs = {k: fa_oracle.rel_fro(gt[k], ref[k]) for k in ("O", "dQ", "dK", "dV")}
+        print(name, {k: "%.2e" % v for k, v in errs.items()},
+              "LSE max abs %.2e" % (ref["LSE"].double() - gt["LSE"]).abs().max().item())
+
+
+if __name__ == "__main__":
+    main()
