@@ -138,23 +138,24 @@ FA_DEVINL void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
 }
 
 // ---- cross-half exchange (lanes l <-> l + 32) -----------------------------
-FA_DEVINL float other_half(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  // r[0] = {own low half replicated}, r[1] = {own high half replicated}; the value that is
-  // not ours is in r[1] for lanes < 32 and in r[0] for lanes >= 32.
-  unsigned o = (threadIdx.x & 32) ? r[0] : r[1];
-  return __builtin_bit_cast(float, o);
+// v_permlane32_swap_b32 vdst, src swaps lanes 32..63 of vdst with lanes 0..31 of src.  Fed two
+// copies of v it leaves a = {low half's values in both halves}, b = {high half's values}.
+// Inline asm on purpose: hipcc (ROCm 7.2) folds the two results of
+// __builtin_amdgcn_permlane32_swap into one when they feed a commutative op (seen in the IR:
+// r[0] + r[1] became r[0] + r[0]), which silently breaks every reduction below.
+FA_DEVINL void swap_halves(float& a, float& b) {
+  // 2 wait states between a VALU write of an operand and the permlane read (s_nop 1)
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 FA_DEVINL float half_max(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float a = v, b = v;
+  swap_halves(a, b);
+  return __builtin_fmaxf(a, b);
 }
 FA_DEVINL float half_sum(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  float a = v, b = v;
+  swap_halves(a, b);
+  return a + b;
 }
 
 // ---- workgroup -> work item, XCD aware ------------------------------------
