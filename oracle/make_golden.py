@@ -96,5 +96,46 @@ def main():
               "LSE max abs %.2e" % (ref["LSE"].double() - gt["LSE"]).abs().max().item())
 
 
+def kats():
+    """Known-answer tests of the harness functions, from the reference's OWN functions:
+    verify_results (code/_verify_func.py:3-40, prints only -> stdout is parsed),
+    naive_attention and the FLOP formula (code/Performance_Comparison.py:101-107,130-144)."""
+    import contextlib
+    import io
+    import json
+    import re
+
+    import _verify_func as RV
+    import Performance_Comparison as RP
+
+    out = {"verify": [], "naive": [], "flops": []}
+    b = torch.linspace(-1, 1, 64).view(8, 8)
+    for eps in (1e-4, 2e-2):
+        t = b + eps * torch.sin(torch.arange(64.0)).view(8, 8)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            RV.verify_results(b, t)
+        txt = buf.getvalue()
+        nums = [float(x) for x in re.findall(r":\s*([-+0-9.e]+)\s*$", txt, flags=re.M)]
+        out["verify"].append({"eps": eps, "max_abs": nums[0], "mean_abs": nums[1], "max_rel": nums[2],
+                              "max_norm": nums[3], "cos": nums[4], "passed": "Passed" in txt})
+    n = 2 * 1 * 4 * 8
+    q = ((torch.arange(n) % 7 - 3) / 4.0).view(2, 1, 4, 8)
+    k = ((torch.arange(n) % 5 - 2) / 3.0).view(2, 1, 4, 8)
+    v = ((torch.arange(n) % 3 - 1) / 2.0).view(2, 1, 4, 8)
+    for causal in (False, True):
+        o = RP.naive_attention(q, k, v, causal)
+        out["naive"].append({"causal": causal, "sum": float(o.sum()), "o": o.flatten().tolist()})
+    for (B, H, S, D, causal) in [(4, 32, 4096, 64, True), (4, 32, 4096, 128, True), (64, 32, 8192, 64, True),
+                                 (2, 4, 256, 64, False), (4, 8, 4096, 64, True)]:
+        f = 4 * B * H * S * S * D // (2 if causal else 1)  # P:101
+        out["flops"].append({"B": B, "H": H, "S": S, "D": D, "causal": causal,
+                             "fwd": f, "bwd": int(2.5 * f), "fwd_bwd": int(3.5 * f)})
+    with open(os.path.join(OUT, "kat.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("kat.json:", out["verify"], [x["sum"] for x in out["naive"]])
+
+
 if __name__ == "__main__":
     main()
+    kats()

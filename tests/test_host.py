@@ -1,0 +1,101 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports what include/mi355fa.h
+declares, rejects bad arguments before launching, and the Python host mirrors the reference's
+call surface (names, argument order, defaults).  No compute is launched here (no GPU)."""
+import ast
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "mi355fa.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fa_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_declares_expected_entry_points():
+    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dq", "fa_fwd", "fa_last_error", "fa_supported"]
+
+
+def test_library_exports_every_declared_symbol():
+    import _mi355fa as fa
+    raw = ctypes.CDLL(fa.LIB_PATH)
+    for name in _header_functions():
+        assert hasattr(raw, name), name
+        assert name in fa.SIGNATURES, "python binding misses " + name
+    assert fa.lib.fa_abi_version() == 1
+    assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
+    assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
+
+
+def test_argument_errors_are_rejected_before_launch():
+    import _mi355fa as fa
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    L = fa.lib
+    assert L.fa_fwd(None, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, None) == -1
+    assert b"NULL" in L.fa_last_error()
+    assert L.fa_fwd(p, p, p, p, p, 0, 1, 8, 8, 64, 1, 0, 0.125, None) == -2
+    assert L.fa_fwd(p, p, p, p, p, 1, 1, 8, 8, 96, 1, 0, 0.125, None) == -3
+    assert b"head dim" in L.fa_last_error()
+    assert L.fa_fwd(p, p, p, p, p, 1, 1, 8, 8, 64, 5, 0, 0.125, None) == -4
+    assert L.fa_fwd(p + 2, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, None) == -5
+    assert L.fa_bwd_dq(p, p, p, p, p, p, p, None, 1, 1, 8, 8, 64, 1, 0, 0.125, None) == -1
+    assert L.fa_bwd_dkv(p, p, p, p, p, p, p, p, 1, 1, 8, 8, 65, 1, 0, 0.125, None) == -3
+    with pytest.raises(RuntimeError, match="head dim"):
+        fa.check(-3, "fa_fwd")
+
+
+def test_python_surface_matches_reference():
+    import My_FlashAttention_optimized as M
+    import _verify_func as V
+    sig = lambda f: [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+    E = inspect.Parameter.empty
+    assert sig(M.flash_attention) == [("Q", E), ("K", E), ("V", E), ("is_causal", False)]          # M:169
+    assert sig(M.flash_attention_forward) == [("Q", E), ("K", E), ("V", E), ("is_causal", E)]      # M:14
+    assert [n for n, _ in sig(M.flash_attention_backward)] == ["Q", "K", "V", "O", "dO", "LSE", "is_causal"]  # M:62
+    assert [n for n, _ in sig(M.compare_with_sdpa)][:4] == ["Q", "K", "V", "is_causal"]           # M:172
+    assert issubclass(M.FlashAttentionFunction, torch.autograd.Function)
+    assert [n for n, _ in sig(M.FlashAttentionFunction.forward)] == ["ctx", "Q", "K", "V", "is_causal"]
+    assert [n for n, _ in sig(M.FlashAttentionFunction.backward)] == ["ctx", "dO"]
+    assert sig(V.verify_results)[:5] == [("bench", E), ("triton_output", E), ("name", "Attention"),
+                                         ("rtol", 1e-2), ("atol", 1e-3)]                           # V:3
+
+
+def test_binding_asserts_like_reference_on_bad_inputs():
+    import My_FlashAttention_optimized as M
+    q = torch.randn(1, 1, 8, 64, dtype=torch.float16)
+    with pytest.raises(AssertionError):  # M:133 is_cuda
+        M.flash_attention(q, q, q)
+
+
+def test_verify_results_kat_and_return_value(capsys):
+    from _util import load_kat
+    import _verify_func as V
+    b = torch.linspace(-1, 1, 64).view(8, 8)
+    for case in load_kat()["verify"]:
+        t = b + case["eps"] * torch.sin(torch.arange(64.0)).view(8, 8)
+        m = V.verify_results(b, t)
+        out = capsys.readouterr().out
+        assert ("Test Passed" in out) == case["passed"] == m["passed"]
+        assert "Max Normalized Error (allclose-style)" in out
+        assert abs(m["max_norm"] - case["max_norm"]) <= 6e-3 * case["max_norm"]
+
+
+def test_host_modules_parse_on_py310_grammar():
+    # the reference's own binding does not parse here (nested same-quote f-strings, M:205-211)
+    for f in ("My_FlashAttention_optimized.py", "_verify_func.py", "Performance_Comparison.py", "_mi355fa.py", "_scaling.py"):
+        ast.parse(open(os.path.join(PKG, f)).read(), feature_version=(3, 10))
+
+
+def test_product_path_does_not_touch_the_oracle():
+    for f in os.listdir(PKG):
+        if f.endswith(".py"):
+            src = open(os.path.join(PKG, f)).read()
+            assert "fa_oracle" not in src and "oracle" not in src.lower().replace("# oracle", ""), f

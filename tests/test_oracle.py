@@ -1,0 +1,95 @@
+"""CPU tests: the oracle against the reference's own outputs (tests/golden, produced by
+oracle/make_golden.py from the reference's Triton kernel bodies) and against fp64 math."""
+import pytest
+import torch
+
+import fa_oracle as fo
+from _util import golden_names, load_golden, load_kat, rand_inputs
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_kernels(name):
+    g = load_golden(name)
+    m = g["meta"]
+    r = fo.fwd_bwd_tiled(g["Q"], g["K"], g["V"], g["dO"], m["causal"], m["BM"], m["BN"])
+    # same algorithm, same rounding points: only fp32 summation order differs (a few fp16 ulps flip)
+    for k in ("O", "dQ", "dK", "dV"):
+        assert fo.rel_fro(g["ref_" + k], r[k]) < 5e-5, k
+        assert (g["ref_" + k].float() - r[k].float()).abs().max() < 4e-3, k
+    assert (g["ref_LSE"] - r["LSE"]).abs().max() < 4e-6
+    assert (g["ref_delta"] - r["delta"]).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_reference_kernels_match_fp64(name):
+    """The pins themselves are sane: reference outputs vs fp64 attention."""
+    g = load_golden(name)
+    m = g["meta"]
+    gt = fo.attention_fp64(g["Q"], g["K"], g["V"], g["dO"], m["causal"])
+    for k in ("O", "dQ", "dK", "dV"):
+        assert fo.rel_fro(gt[k], g["ref_" + k]) < 1e-3, k  # BASELINE "within 1e-3 rel"
+        assert fo.verify_metrics(gt[k], g["ref_" + k])["passed"], k
+    assert (g["ref_LSE"].double() - gt["LSE"]).abs().max() < 1e-3  # Phase_3.md:752-753
+    assert (g["ref_delta"].double() - gt["delta"]).abs().max() < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 500, 500, 64, True), (1, 2, 500, 500, 64, False),
+                                   (1, 1, 77, 333, 64, False), (1, 2, 384, 128, 64, True),
+                                   (1, 1, 200, 200, 128, True)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_oracle_ragged_and_cross_vs_fp64(shape, dtype):
+    """Masked tails (Phase-3/4 semantics): any S_q, S_k; where the reference's descriptor path is wrong."""
+    B, H, Sq, Sk, D, causal = shape
+    Q, K, V, dO = rand_inputs(B, H, Sq, Sk, D, dtype, seed=3)
+    gt = fo.attention_fp64(Q, K, V, dO, causal)
+    r = fo.fwd_bwd_tiled(Q, K, V, dO, causal, 64, 64)
+    tol = 1e-3 if dtype == torch.float16 else 8e-3
+    for k in ("O", "dQ", "dK", "dV"):
+        assert fo.rel_fro(gt[k], r[k]) < tol, (k, fo.rel_fro(gt[k], r[k]))
+    assert (r["LSE"].double() - gt["LSE"]).abs().max() < 1e-3
+
+
+def test_oracle_tile_config_insensitive():
+    Q, K, V, dO = rand_inputs(1, 2, 256, 256, 64, torch.float16, seed=5)
+    a = fo.fwd_bwd_tiled(Q, K, V, dO, True, 64, 64)
+    b = fo.fwd_bwd_tiled(Q, K, V, dO, True, 32, 64)
+    for k in ("O", "dQ", "dK", "dV"):
+        assert fo.rel_fro(a[k], b[k]) < 1e-4
+
+
+def test_fp64_matches_torch_sdpa():
+    Q, K, V, dO = rand_inputs(2, 2, 96, 160, 64, torch.float32, seed=7)
+    for causal in (False, True):
+        gt = fo.attention_fp64(Q, K, V, dO, causal)
+        o = torch.nn.functional.scaled_dot_product_attention(Q.double(), K.double(), V.double(), is_causal=causal)
+        assert torch.allclose(gt["O"], o, atol=1e-12)
+
+
+def test_verify_metrics_kat():
+    kat = load_kat()["verify"]
+    b = torch.linspace(-1, 1, 64).view(8, 8)
+    for case in kat:
+        t = b + case["eps"] * torch.sin(torch.arange(64.0)).view(8, 8)
+        m = fo.verify_metrics(b, t)
+        assert m["passed"] == case["passed"]
+        for k in ("max_abs", "mean_abs", "max_rel", "max_norm"):
+            assert abs(m[k] - case[k]) <= 6e-3 * abs(case[k]), k  # the reference prints 3 digits
+        assert abs(m["cos"] - case["cos"]) < 2e-6
+
+
+def test_naive_attention_kat():
+    n = 2 * 1 * 4 * 8
+    q = ((torch.arange(n) % 7 - 3) / 4.0).view(2, 1, 4, 8)
+    k = ((torch.arange(n) % 5 - 2) / 3.0).view(2, 1, 4, 8)
+    v = ((torch.arange(n) % 3 - 1) / 2.0).view(2, 1, 4, 8)
+    for case in load_kat()["naive"]:
+        o = fo.naive_attention(q, k, v, case["causal"])
+        assert torch.allclose(o.flatten(), torch.tensor(case["o"]), atol=1e-6)
+
+
+def test_flops_kat():
+    for c in load_kat()["flops"]:
+        for mode in ("fwd", "bwd", "fwd_bwd"):
+            assert fo.attention_flops(c["B"], c["H"], c["S"], c["S"], c["D"], c["causal"], mode) == c[mode]
+    assert fo.attention_flops(4, 32, 4096, 4096, 64, True, "fwd") == 274_877_906_944
+    assert fo.attention_flops(4, 32, 4096, 4096, 64, True, "fwd_bwd") == 962_072_674_304
