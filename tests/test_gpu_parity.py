@@ -102,14 +102,20 @@ def test_against_fp64_oracle(shape, dtype):
     gt = fo.attention_fp64(Q, K, V, dO, causal)
     r = run_gpu_raw(Q, K, V, dO, causal)
     assert (r["LSE"].double() - gt["LSE"]).abs().max() < 1e-3
-    assert (r["delta"].double() - gt["delta"]).abs().max() < (2e-2 if dtype == BF16 else 5e-3)
+    # delta is computed from the ROUNDED O as in the reference (K:210-211): its error is |dO| * ulp(O) * sqrt(D)
+    assert (r["delta"].double() - gt["delta"]).abs().max() < (1e-1 if dtype == BF16 else 1.5e-2)
+    names = ["O", "dQ", "dK", "dV"]
+    for k in list(names):
+        if gt[k].abs().max() < 1e-9:        # a single visible key: softmax is constant, dQ = dK = 0 exactly
+            assert r[k].float().abs().max() < 2e-3, k
+            names.remove(k)
     if dtype == F16:
-        for k in ("O", "dQ", "dK", "dV"):
+        for k in names:
             assert fo.rel_fro(gt[k], r[k]) < 1e-3, (k, fo.rel_fro(gt[k], r[k]))
             assert fo.verify_metrics(gt[k], r[k])["passed"], k
     else:
         peer = dict(zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))  # PyTorch's own bf16 SDPA (CPU)
-        for k in ("O", "dQ", "dK", "dV"):
+        for k in names:
             ours, theirs = fo.rel_fro(gt[k], r[k]), fo.rel_fro(gt[k], peer[k])
             assert ours < max(2 * theirs, 4e-3), (k, ours, theirs)
             assert fo.verify_metrics(gt[k], r[k], rtol=2e-2, atol=2e-2)["cos"] > 0.999
