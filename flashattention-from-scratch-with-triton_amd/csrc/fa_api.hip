@@ -8,6 +8,7 @@
 namespace {
 
 thread_local char g_err[256] = "";
+void* g_dbg = nullptr;  // set by fa_debug_set_buffer(); read by -DFA_STAMPS builds only
 
 int fail(int code, const char* fmt, const char* what) {
   snprintf(g_err, sizeof(g_err), fmt, what);
@@ -40,6 +41,9 @@ extern "C" {
 
 int fa_abi_version(void) { return MI355FA_ABI_VERSION; }
 
+// Not part of the public header: diagnostic hook used by tools/stamps.py with -DFA_STAMPS builds.
+void fa_debug_set_buffer(void* p) { g_dbg = p; }
+
 const char* fa_last_error(void) { return g_err; }
 
 int fa_supported(int D, int dtype) {
@@ -52,7 +56,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int
   if (int rc = check_common("fa_fwd", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd");
-  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0};
+  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg};
   hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_fwd launch");
   return 0;

@@ -14,6 +14,8 @@
 //   reductions plus one lane<->lane+32 exchange, the rescale is a per-lane scalar,
 //   and the fp32 P^T accumulator is, after rounding, directly the B operand of
 //   O^T += V^T P^T (V^T fetched with ds_read_b64_tr_b16) -- P never touches LDS.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "fa_common.h"
@@ -35,8 +37,27 @@ struct FwdCfg {
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2], V[2]
 };
 
+// Diagnostic build only (-DFA_STAMPS): per-wave cycle shares of the loop segments, accumulated in
+// SGPRs and written to a side buffer (FwdParams::dbg) that nothing else reads.
+#ifdef FA_STAMPS
+#define FA_STAMP(slot)                                                            \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long now_;                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += now_ - last_;                                                    \
+    last_ = now_;                                                                 \
+  } while (0)
+#else
+#define FA_STAMP(slot) do {} while (0)
+#endif
+
+// Online-softmax rescale is deferred until a row max grows by more than 2^kDeferLog2 (see tile()).
+constexpr float kDeferLog2 = 6.0f;
+
 template <int D, typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(256, (D == 64 ? 3 : 1)) void fa_fwd_kernel(FwdParams p) {
   using C = FwdCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -96,6 +117,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParam
     for (int db = 0; db < C::DB; ++db) v_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
 
   const float c2 = p.scale * kLog2e;  // exp(x*scale) = exp2(x*c2)
+  const float defer_raw = kDeferLog2 / c2;  // rescale threshold in raw-score units
   float m = -INFINITY;                // running row max of the RAW scores (before scale)
   float l = 0.f;                      // this lane's partial row sum (its 16 of every 32 keys)
   f32x16 oacc[C::DB];
@@ -123,11 +145,19 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParam
     }
   };
 
+#ifdef FA_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+#endif
   // One 64-key tile for this wave.  MASKED = false: every key visible to every row.
-  auto tile = [&](int t, auto masked_tag) {
+  // BUF = 0/1: LDS buffer known at compile time (offsets fold into the ds_read immediates);
+  // BUF = -1: taken from t at run time (the few masked tiles).
+  auto tile = [&](int t, auto buf_tag, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
-    const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
+    constexpr int BUF = decltype(buf_tag)::value;
+    const int buf = BUF >= 0 ? BUF : (t & 1);
+    const FA_LDS char* kt = smem + buf * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + (2 + buf) * C::TILE_BYTES;
     const int s0 = t * C::BN;
     bool use[2] = {true, true};
     if constexpr (MASKED) {
@@ -165,13 +195,18 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParam
       }
     }
     // ---- online softmax (query on the lane) ----
-    float tm = sacc[0][0];
+    float tm0 = sacc[0][0], tm1 = sacc[1][0];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) tm = __builtin_fmaxf(tm, sacc[0][i]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tm = __builtin_fmaxf(tm, sacc[1][i]);
-    tm = half_max(tm);
-    if (__builtin_amdgcn_ballot_w64(tm > m) != 0) {  // wave-uniform: some row's max grew
+    for (int i = 1; i < 16; ++i) {
+      tm0 = __builtin_fmaxf(tm0, sacc[0][i]);
+      tm1 = __builtin_fmaxf(tm1, sacc[1][i]);
+    }
+    const float tm = half_max(__builtin_fmaxf(tm0, tm1));
+    FA_STAMP(1);  // S^T MFMAs + row max
+    // Deferred rescale: the running max is only raised when some row's tile max exceeds it by
+    // more than kDefer (in log2 units), so P stays <= 2^kDefer (exact in fp32, same RELATIVE
+    // rounding in 16 bit) and the O-wide multiply is rare.  m = -inf (first tile) always fires.
+    if (__builtin_amdgcn_ballot_w64(tm > m + defer_raw) != 0) {
       const float mn = __builtin_fmaxf(m, tm);
       const float corr = __builtin_amdgcn_exp2f((m - mn) * c2);  // m = -inf -> 0
       l *= corr;
@@ -182,16 +217,17 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParam
       m = mn;
     }
     const float mc = m * c2;
-    float ls = 0.f;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][i], c2, -mc));
         sacc[b][i] = pe;
-        ls += pe;
+        ls[i & 3] += pe;
       }
-    l += ls;
+    l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    FA_STAMP(2);  // rescale + exp + row sum
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -209,34 +245,66 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_fwd_kernel(FwdParam
     }
   };
 
+  // one loop iteration: prefetch tile t+1 to registers, compute tile t, park t+1 in the other buffer
+  auto iter = [&](int t, auto buf_tag, auto masked_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1);
+    FA_STAMP(0);  // issue of the prefetch
+    tile(t, buf_tag, masked_tag);
+    FA_STAMP(3);  // P pack + PV MFMAs
+    if (more) stage_write(BUF >= 0 ? (BUF ^ 1) : ((t + 1) & 1));
+    FA_STAMP(4);  // vmcnt wait + ds_write
+    __syncthreads();
+    FA_STAMP(5);  // barrier
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using BR = std::integral_constant<int, -1>;
+
   // ---- main loop: one barrier per tile; every wave runs exactly ntiles iterations ----
-  // (two loops so the unmasked body has no control-flow merge with the masked one)
   stage_load(0);
   stage_write(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q fragments landed, nothing pending enters the loop
   __syncthreads();
+#ifdef FA_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+  const unsigned long long begin_ = last_;
+#endif
   int t = 0;
-  for (; t < nfull; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) stage_load(t + 1);
-    tile(t, std::false_type{});
-    if (more) stage_write((t + 1) & 1);
-    __syncthreads();
+  for (; t + 2 <= nfull; t += 2) {  // unmasked tiles, two per trip so that the LDS buffer is a constant
+    iter(t, B0{}, std::false_type{});
+    iter(t + 1, B1{}, std::false_type{});
   }
-  for (; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) stage_load(t + 1);
-    tile(t, std::true_type{});
-    if (more) stage_write((t + 1) & 1);
-    __syncthreads();
+  if (t < nfull) {
+    iter(t, B0{}, std::false_type{});
+    ++t;
   }
+  for (; t < ntiles; ++t) iter(t, BR{}, std::true_type{});
 
   // ---- epilogue ----
+#ifdef FA_STAMPS
+  const unsigned long long loop_end_ = last_;
+#endif
   const float lt = half_sum(l);
   const float inv = 1.0f / lt;
   // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
   store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * C::ROWB, lane);
   if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * p.scale + __builtin_logf(lt));
+#ifdef FA_STAMPS
+  if (p.dbg && lane == 0) {
+    unsigned long long end_;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(end_)::"memory");
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+    for (int i = 0; i < 6; ++i) d[i] = seg[i];
+    d[6] = loop_end_ - begin_;   // loop
+    d[7] = end_ - loop_end_;     // epilogue
+    d[8] = ntiles;
+    d[9] = nfull;
+    d[10] = begin_;
+    d[11] = end_;
+  }
+#endif
 }
 
 // ---- host launcher ----------------------------------------------------------
@@ -253,7 +321,12 @@ static hipError_t launch(const FwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v2.hip
+
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  // D = 64 runs the 256-row / LDS-DMA schedule; FA_FWD_V1=1 selects the first-generation kernel (A/B only)
+  static const bool use_v1 = getenv("FA_FWD_V1") != nullptr;
+  if (D == 64 && !use_v1) return launch_fwd_v2(p, dtype, causal, s);
   p.nq_tiles = (p.Sq + 127) / 128;
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);

@@ -1,0 +1,406 @@
+// FlashAttention forward, head dim 64, second-generation schedule for gfx950.
+//
+// Same maths and rounding points as fa_fwd.hip (reference kernel
+// code/_flash_attention_kernel_optimized.py:35-129); what changes is the mapping:
+//
+//   * workgroup = 4 waves = 256 query rows; every wave owns TWO 32-row query blocks.  Per K/V tile
+//     a wave therefore does twice the MFMA work for the same staging / barrier cost, K/V cross
+//     the L2 -> LDS path half as often, and the two query blocks give the wave two independent
+//     dependency chains: the S^T MFMAs of block 1 run under the softmax VALU of block 0, the
+//     P V MFMAs of block 0 under the softmax of block 1.
+//   * K/V tiles (64 keys) go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) into a
+//     3-deep ring, two tiles ahead: no staging VGPRs, no ds_write pass, and the wait that
+//     retires tile t+1 (a counted vmcnt) never has to wait -- the loads are a full tile old.
+//     The image swizzle is applied to the per-lane SOURCE address (the DMA destination is
+//     wave-linear), reads use the same XOR (fa_common.h, lds_off).
+//   * one raw s_barrier per tile (no vmcnt(0) drain: the next tile's DMA stays in flight).
+#include <type_traits>
+
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+constexpr float kDeferLog2V2 = 6.0f;  // see fa_fwd.hip: deferred online-softmax rescale
+
+struct Fwd2Cfg {
+  static constexpr int D = 64;
+  static constexpr int BM = 256, BN = 64, NT = 256, NW = 4;
+  static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
+  static constexpr int TILE_BYTES = BN * ROWB;        // 8 KiB per matrix
+  static constexpr int RING = 3;
+  static constexpr int V_BASE = RING * TILE_BYTES;    // K ring, then V ring
+  static constexpr int LDS_BYTES = 2 * RING * TILE_BYTES;  // 48 KiB
+  static constexpr int DMA_PER_MAT = TILE_BYTES / (NW * 1024);  // 1-KiB DMA instructions per wave per matrix
+};
+
+#ifdef FA_STAMPS
+#define FA_STAMP(slot)                                                            \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long now_;                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += now_ - last_;                                                    \
+    last_ = now_;                                                                 \
+  } while (0)
+#else
+#define FA_STAMP(slot) do {} while (0)
+#endif
+
+// s_waitcnt vmcnt(n) only (lgkmcnt / expcnt untouched), n < 16
+#define FA_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
+  using C = Fwd2Cfg;
+  using vec8 = typename T::vec8;
+  constexpr int D = C::D;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FA_LDS char* smem = (FA_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = w / p.nq_tiles;
+  int qt = w - bh * p.nq_tiles;
+  if (CAUSAL) qt = p.nq_tiles - 1 - qt;  // heaviest tiles first
+  const int q0_wg = qt * C::BM;
+  const int qw0 = q0_wg + wave * 64;
+
+  const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
+  const char* kb = (const char*)p.k + (size_t)bh * p.Sk * C::ROWB;
+  const char* vb = (const char*)p.v + (size_t)bh * p.Sk * C::ROWB;
+  char* ob = (char*)p.o + (size_t)bh * p.Sq * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)p.Sq * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+
+  // ---- tile schedule (wave-uniform) ----
+  const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
+  const int ntiles = (kv_end + C::BN - 1) / C::BN;                    // tiles the workgroup streams
+  int n_mine = CAUSAL ? min(ntiles, qw0 / C::BN + 1) : ntiles;        // tiles this wave computes
+  if (qw0 >= p.Sq) n_mine = 0;                                        // wave entirely past the last row
+  const int nfull = min(n_mine, CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN);  // unmasked ones
+
+  // A DMA whose source is out of range may leave its LDS bytes untouched; a ragged last tile must
+  // not expose uninitialised LDS (0 * NaN in P V), so clear the ring once.  Later rounds only ever
+  // leave finite stale K/V there.
+  if (p.Sk % C::BN != 0) {
+    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    __syncthreads();
+  }
+
+  // ---- LDS-DMA: wave w fills rows [16w, 16w+16) of the K and V tile, 8 rows (1 KiB) per instruction.
+  // lane p of instruction i lands on LDS row 16w + 8i + p/8, physical chunk p%8; it must therefore
+  // FETCH the logical chunk (p%8) ^ f(row) of that row.
+  int dma_src[C::DMA_PER_MAT];
+#pragma unroll
+  for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+    const int row = 16 * wave + 8 * i + (lane >> 3);
+    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane & 7) * 16;
+  }
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {  // buf: compile-time constant at every call site
+    const int soff = t * C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+      const int dst = buf * C::TILE_BYTES + (16 * wave + 8 * i) * C::ROWB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (FA_LDS void*)(smem + dst), 16, dma_src[i], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (FA_LDS void*)(smem + C::V_BASE + dst), 16, dma_src[i], soff, 0, 0);
+    }
+  };
+  constexpr int DMA_PER_TILE = 2 * C::DMA_PER_MAT;  // vmcnt units per tile per wave
+
+  // prologue: tiles 0 and 1 in flight, then the Q fragments
+  dma_tile(0, 0);
+  if (ntiles > 1) dma_tile(1, 1);
+
+  // ---- Q^T fragments (B operand) of both query blocks, resident ----
+  vec8 qf[2][C::KS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks)
+      qf[j][ks] = as_vec8<T>(buf_load16(rq, (qw0 + 32 * j + r) * C::ROWB + (2 * ks + h) * 16));
+
+  int k_off[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) k_off[ks] = lds_off<D>(r, 2 * ks + h);
+  int v_off[2][C::DB];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) v_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
+
+  const float c2 = p.scale * kLog2e;
+  const float defer_raw = kDeferLog2V2 / c2;
+  float m[2] = {-INFINITY, -INFINITY};
+  float l[2] = {0.f, 0.f};
+  f32x16 oacc[2][C::DB];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[j][db][i] = 0.f;
+
+#ifdef FA_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0, begin_ = 0;
+#endif
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  // S^T of query block j against the 64 keys of the tile (two 32-key blocks)
+  auto scores = [&](const FA_LDS char* kt, auto jt, f32x16 (&s)[2]) __attribute__((always_inline)) {
+    constexpr int j = decltype(jt)::value;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[b][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
+        s[b] = T::mfma(a, qf[j][ks], s[b]);
+      }
+    }
+  };
+  // running max update of block j (deferred rescale); returns nothing, O/l/m updated in place
+  auto row_max = [&](auto jt, const f32x16 (&s)[2]) __attribute__((always_inline)) {
+    constexpr int j = decltype(jt)::value;
+    float t0 = s[0][0], t1 = s[1][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      t0 = __builtin_fmaxf(t0, s[0][i]);
+      t1 = __builtin_fmaxf(t1, s[1][i]);
+    }
+    const float tm = half_max(__builtin_fmaxf(t0, t1));
+    if (__builtin_amdgcn_ballot_w64(tm > m[j] + defer_raw) != 0) {
+      const float mn = __builtin_fmaxf(m[j], tm);
+      const float corr = __builtin_amdgcn_exp2f((m[j] - mn) * c2);
+      l[j] *= corr;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[j][db][i] *= corr;
+      m[j] = mn;
+    }
+  };
+  // p = exp2(s*c2 - m*c2), row-sum into l, round to the 16-bit B fragments
+  auto probs = [&](auto jt, f32x16 (&s)[2], vec8 (&pf)[2][2]) __attribute__((always_inline)) {
+    constexpr int j = decltype(jt)::value;
+    const float mc = m[j] * c2;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][i], c2, -mc));
+        s[b][i] = pe;
+        ls[i & 3] += pe;
+      }
+    l[j] += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      pf[b][0] = pack8<T, 0>(s[b]);
+      pf[b][1] = pack8<T, 1>(s[b]);
+    }
+  };
+  // O^T[j] += V^T P^T
+  auto pv = [&](const FA_LDS char* vt, auto jt, const vec8 (&pf)[2][2], bool use0, bool use1) __attribute__((always_inline)) {
+    constexpr int j = decltype(jt)::value;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (!(b == 0 ? use0 : use1)) continue;
+      const FA_LDS char* base = vt + b * 32 * C::ROWB;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        vec8 a0 = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
+        oacc[j][db] = T::mfma(a0, pf[b][0], oacc[j][db]);
+        vec8 a1 = lds_read_tr_frag<T>(base + 16 * C::ROWB + v_off[0][db], base + 16 * C::ROWB + v_off[1][db]);
+        oacc[j][db] = T::mfma(a1, pf[b][1], oacc[j][db]);
+      }
+    }
+  };
+
+  // unmasked tile: every key of the tile visible to all 64 rows of the wave.
+  // Both query blocks consume each K / V fragment as soon as it is read (one LDS read, two MFMAs):
+  // per tile 8 ds_read_b128 + 16 transposed reads feed 32 MFMAs.  The MFMA phases of this wave run
+  // under the softmax phase of the other wave on the SIMD (different workgroup, not barrier-locked).
+  auto tile_full = [&](int buf) __attribute__((always_inline)) {
+    const FA_LDS char* kt = smem + buf * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + C::V_BASE + buf * C::TILE_BYTES;
+    f32x16 s0[2], s1[2];
+    vec8 p0[2][2], p1[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s0[b][i] = 0.f;
+        s1[b][i] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
+        s0[b] = T::mfma(a, qf[0][ks], s0[b]);
+        s1[b] = T::mfma(a, qf[1][ks], s1[b]);
+      }
+    }
+    FA_STAMP(1);  // S^T MFMAs
+    row_max(J0{}, s0);
+    row_max(J1{}, s1);
+    FA_STAMP(2);  // row max (+ rare rescale)
+    probs(J0{}, s0, p0);
+    probs(J1{}, s1, p1);
+    FA_STAMP(3);  // exp / sum / pack
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const FA_LDS char* base = vt + b * 32 * C::ROWB;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        vec8 a0 = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
+        oacc[0][db] = T::mfma(a0, p0[b][0], oacc[0][db]);
+        oacc[1][db] = T::mfma(a0, p1[b][0], oacc[1][db]);
+        vec8 a1 = lds_read_tr_frag<T>(base + 16 * C::ROWB + v_off[0][db], base + 16 * C::ROWB + v_off[1][db]);
+        oacc[0][db] = T::mfma(a1, p0[b][1], oacc[0][db]);
+        oacc[1][db] = T::mfma(a1, p1[b][1], oacc[1][db]);
+      }
+    }
+  };
+  // masked tile (causal diagonal and/or ragged key tail); rare, so no overlap games
+  auto tile_masked = [&](int t, int buf) __attribute__((always_inline)) {
+    const FA_LDS char* kt = smem + buf * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + C::V_BASE + buf * C::TILE_BYTES;
+    const int s0k = t * C::BN;
+    auto one = [&](auto jt) __attribute__((always_inline)) {
+      constexpr int j = decltype(jt)::value;
+      const int qb0 = qw0 + 32 * j;
+      bool use[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) use[b] = (s0k + 32 * b < p.Sk) && (!CAUSAL || s0k + 32 * b <= qb0);
+      if (!use[0] && !use[1]) return;
+      f32x16 s[2];
+      vec8 pf[2][2];
+      scores(kt, jt, s);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = s0k + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool dead = !use[b] || (CAUSAL && key > qb0 + r) || key >= p.Sk;
+          s[b][i] = dead ? -INFINITY : s[b][i];
+        }
+      row_max(jt, s);
+      probs(jt, s, pf);
+      pv(vt, jt, pf, use[0], use[1]);
+    };
+    one(J0{});
+    one(J1{});
+  };
+
+  // retire tile t+1 (everything but the DMA just issued), then let every wave leave tile t
+  auto ring_sync = [&](bool fetched) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");  // keep LDS reads / DMA issue on their side of the barrier
+    if (fetched) FA_WAIT_VMCNT(DMA_PER_TILE); else FA_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // one ring step on an unmasked tile: tile t lives in buffer BUF, tile t+2 goes to buffer (BUF+2)%3
+  auto step_full = [&](int t, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const bool fetch = t + 2 < ntiles;
+    if (fetch) dma_tile(t + 2, (BUF + 2) % 3);
+    FA_STAMP(0);  // DMA issue
+    tile_full(BUF);
+    FA_STAMP(4);  // P V MFMAs
+    ring_sync(fetch);
+    FA_STAMP(5);  // vmcnt + barrier
+  };
+  // the remaining steps of the workgroup: this wave's masked tile(s), then tiles it only helps stream
+  auto step_tail = [&](int t) __attribute__((always_inline)) {
+    const int buf = t % 3;
+    const bool fetch = t + 2 < ntiles;
+    if (fetch) dma_tile(t + 2, (t + 2) % 3);
+    if (t < n_mine) tile_masked(t, buf);
+    ring_sync(fetch);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
+
+  // tile 0 landed (Q fragments too: they were issued after tile 1's DMA, so wait for everything)
+  asm volatile("" ::: "memory");
+  FA_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // (separate loops: the unmasked body must not share a control-flow merge with the masked one,
+  //  or the accumulators get copied at every join)
+#ifdef FA_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+  begin_ = last_;
+#endif
+  int t = 0;
+  for (; t + 3 <= nfull; t += 3) {
+    step_full(t, B0{});
+    step_full(t + 1, B1{});
+    step_full(t + 2, B2{});
+  }
+  if (t < nfull) {
+    step_full(t, B0{});
+    ++t;
+    if (t < nfull) {
+      step_full(t, B1{});
+      ++t;
+    }
+  }
+  for (; t < ntiles; ++t) step_tail(t);
+
+#ifdef FA_STAMPS
+  unsigned long long loop_end_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(loop_end_)::"memory");
+#endif
+  // ---- epilogue: all waves are past the last barrier, the ring is free for staging O ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float lt = half_sum(l[j]);
+    const float inv = 1.0f / lt;
+    store_tile_rows<D, T>(oacc[j], inv, smem + (wave * 2 + j) * 32 * C::ROWB, ro, (qw0 + 32 * j) * C::ROWB, lane);
+    if (h == 0) buf_store_f32(rl, (qw0 + 32 * j + r) * 4, m[j] * p.scale + __builtin_logf(lt));
+  }
+#ifdef FA_STAMPS
+  if (p.dbg && lane == 0) {
+    unsigned long long end_;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(end_)::"memory");
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+    for (int i = 0; i < 6; ++i) d[i] = seg[i];
+    d[6] = loop_end_ - begin_;
+    d[7] = end_ - loop_end_;
+    d[8] = nfull;   // stamped (unmasked) tiles only
+    d[9] = ntiles;
+    d[10] = begin_;
+    d[11] = end_;
+  }
+#endif
+}
+
+template <typename T, bool CAUSAL>
+static hipError_t launch2(const FwdParams& p, hipStream_t s) {
+  using C = Fwd2Cfg;
+  const int grid = p.nq_tiles * p.B * p.H;
+  auto kern = fa_fwd2_kernel<T, CAUSAL>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s) {
+  p.nq_tiles = (p.Sq + Fwd2Cfg::BM - 1) / Fwd2Cfg::BM;
+  if (dtype == 1) return causal ? launch2<BF16, true>(p, s) : launch2<BF16, false>(p, s);
+  return causal ? launch2<FP16, true>(p, s) : launch2<FP16, false>(p, s);
+}
+
+}  // namespace fa

@@ -13,6 +13,7 @@ struct FwdParams {
   int B, H, Sq, Sk;
   float scale;
   int nq_tiles;  // filled by the launcher
+  void* dbg;     // diagnostic builds (-DFA_STAMPS) only: cycle-stamp buffer, else unused
 };
 
 struct BwdParams {
