@@ -17,6 +17,8 @@
 //     dP = dO V^T - delta    (A = dO rows, B = V^T resident; -delta[q] preloaded as C)
 // have the query index in the accumulator REGISTER, so P and dS = P o dP are, after
 // rounding, directly the B operands of dV^T += dO^T P and dK^T += Q^T dS.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "fa_common.h"
@@ -248,7 +250,11 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_bwd_dkv_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v2.hip
+
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  static const bool use_v1 = getenv("FA_DKV_V1") != nullptr;  // A/B only
+  if (D == 64 && !use_v1) return launch_bwd_dkv_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);

@@ -17,6 +17,8 @@
 // so LSE / delta are per-lane scalars and dS^T = P^T o dP^T, rounded, is directly the
 // B operand of dQ^T += K^T dS^T (K^T fetched from the same LDS image by
 // ds_read_b64_tr_b16).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "fa_common.h"
@@ -212,7 +214,11 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v2.hip
+
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  static const bool use_v1 = getenv("FA_DQ_V1") != nullptr;  // A/B only
+  if (D == 64 && !use_v1) return launch_bwd_dq_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sq + 127) / 128;
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);

@@ -137,6 +137,21 @@ FA_DEVINL void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
 
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds): 64 lanes x 16 B from per-lane global offsets `voff`
+// (+ wave-uniform `soff`) to the 1 KiB of LDS starting at byte address `lds_addr` (wave-uniform).
+// Inline asm on purpose: the builtin form makes hipcc drain vmcnt(0) before any later LDS read it
+// cannot disambiguate (every ds_read_b64_tr_b16) and at every memory clobber, which serialises the
+// prefetch ring.  The compiler does not count these loads: the kernels retire them with explicit
+// counted s_waitcnt vmcnt(N) + s_barrier.  M0 (the DMA's LDS base) is saved and restored.
+FA_DEVINL void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, int voff, int soff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
+FA_DEVINL unsigned lds_addr_of(const FA_LDS char* p) { return (unsigned)(uintptr_t)p; }
+
 // ---- cross-half exchange (lanes l <-> l + 32) -----------------------------
 // v_permlane32_swap_b32 vdst, src swaps lanes 32..63 of vdst with lanes 0..31 of src.  Fed two
 // copies of v it leaves a = {low half's values in both halves}, b = {high half's values}.

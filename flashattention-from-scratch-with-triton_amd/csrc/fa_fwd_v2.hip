@@ -64,12 +64,19 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
+  // Work list: non-causal -> one 256-row query tile per workgroup.  Causal -> query tile i costs i+1
+  // K/V steps, so each workgroup takes the PAIR (nq-1-i, i): every workgroup then streams nq+1 steps
+  // and the grid is perfectly balanced (heavy tile first).
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = w / p.nq_tiles;
-  int qt = w - bh * p.nq_tiles;
-  if (CAUSAL) qt = p.nq_tiles - 1 - qt;  // heaviest tiles first
+  const int per_bh = CAUSAL ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
+  const int bh = w / per_bh;
+  const int idx = w - bh * per_bh;
+  const int npass = (CAUSAL && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qt = CAUSAL ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : idx;
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 64;
+  if (pass) __syncthreads();  // the previous pass staged its O tile in the ring
 
   const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
   const char* kb = (const char*)p.k + (size_t)bh * p.Sk * C::ROWB;
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
 #pragma unroll
     for (int i = 0; i < C::DMA_PER_MAT; ++i) {
       const int dst = buf * C::TILE_BYTES + (16 * wave + 8 * i) * C::ROWB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (FA_LDS void*)(smem + dst), 16, dma_src[i], soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (FA_LDS void*)(smem + C::V_BASE + dst), 16, dma_src[i], soff, 0, 0);
+      dma16(rk, lds_addr_of(smem + dst), dma_src[i], soff);
+      dma16(rv, lds_addr_of(smem + C::V_BASE + dst), dma_src[i], soff);
     }
   };
   constexpr int DMA_PER_TILE = 2 * C::DMA_PER_MAT;  // vmcnt units per tile per wave
@@ -386,12 +393,13 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     d[11] = end_;
   }
 #endif
+  }  // pass
 }
 
 template <typename T, bool CAUSAL>
 static hipError_t launch2(const FwdParams& p, hipStream_t s) {
   using C = Fwd2Cfg;
-  const int grid = p.nq_tiles * p.B * p.H;
+  const int grid = (CAUSAL ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
   auto kern = fa_fwd2_kernel<T, CAUSAL>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();
