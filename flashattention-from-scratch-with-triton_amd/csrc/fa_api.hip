@@ -69,7 +69,7 @@ int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const 
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
       misaligned(dq) || misaligned(delta))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq");
-  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0};
+  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg};
   hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
   return 0;
@@ -83,7 +83,7 @@ int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, co
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
       misaligned(dk) || misaligned(dv))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv");
-  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0};
+  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg};
   hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
   return 0;

@@ -251,10 +251,12 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 }
 
 hipError_t launch_bwd_dkv_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v2.hip
+hipError_t launch_bwd_dkv_v3(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v3.hip
 
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  static const bool use_v1 = getenv("FA_DKV_V1") != nullptr;  // A/B only
-  if (D == 64 && !use_v1) return launch_bwd_dkv_v2(p, dtype, causal, s);
+  static const int impl = getenv("FA_DKV_IMPL") ? atoi(getenv("FA_DKV_IMPL")) : 2;  // 2 = default; 1, 3: other schedules (A/B only)
+  if (D == 64 && impl == 3) return launch_bwd_dkv_v3(p, dtype, causal, s);
+  if (D == 64 && impl == 2) return launch_bwd_dkv_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);

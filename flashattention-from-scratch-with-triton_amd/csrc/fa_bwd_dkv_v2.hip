@@ -32,6 +32,20 @@ struct Dkv2Cfg {
   static constexpr int DMA_PER_MAT = TILE_BYTES / (NW * 1024);
 };
 
+#ifdef FA_STAMPS
+#define FA_STAMP(slot)                                                            \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long now_;                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += now_ - last_;                                                    \
+    last_ = now_;                                                                 \
+  } while (0)
+#else
+#define FA_STAMP(slot) do {} while (0)
+#endif
+
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   using C = Dkv2Cfg;
@@ -86,6 +100,10 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     __syncthreads();
   }
 
+#ifdef FA_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0, nblk_ = 0;
+#endif
   for (int pass = 0; pass < npass; ++pass) {
     const int kt_idx = CAUSAL ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
     const int k0_wg = kt_idx * C::BK;
@@ -195,6 +213,21 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
         pacc = T::mfma(a, vf[ks], pacc);
       }
       hook(1);
+      FA_STAMP(1);  // row-constant + row-fragment reads, S and dP MFMA chains
+      // transposed fragments for dV^T / dK^T: issued BEFORE the exp / dS arithmetic (order pinned) so that
+      // their LDS latency is covered by it; left alone hipcc reads each one right before its MFMA
+      vec8 dof[C::DB][2], qtf[C::DB][2];
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        dof[db][0] = lds_read_tr_frag<T>(dbp + tr_off[0][db], dbp + tr_off[1][db]);
+        dof[db][1] = lds_read_tr_frag<T>(dbp + 16 * C::ROWB + tr_off[0][db], dbp + 16 * C::ROWB + tr_off[1][db]);
+      }
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        qtf[db][0] = lds_read_tr_frag<T>(qbp + tr_off[0][db], qbp + tr_off[1][db]);
+        qtf[db][1] = lds_read_tr_frag<T>(qbp + 16 * C::ROWB + tr_off[0][db], qbp + 16 * C::ROWB + tr_off[1][db]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float x = __builtin_fmaf(sacc[i], c2, nl[i]);
@@ -208,20 +241,22 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       }
       const vec8 p0 = pack8<T, 0>(sacc), p1 = pack8<T, 1>(sacc);
       const vec8 s0 = pack8<T, 0>(pacc), s1 = pack8<T, 1>(pacc);
+      __builtin_amdgcn_sched_barrier(0);
+      FA_STAMP(2);  // tr reads + exp / dS / pack
 #pragma unroll
       for (int db = 0; db < C::DB; ++db) {
-        vec8 a0 = lds_read_tr_frag<T>(dbp + tr_off[0][db], dbp + tr_off[1][db]);
-        dvacc[db] = T::mfma(a0, p0, dvacc[db]);
-        vec8 a1 = lds_read_tr_frag<T>(dbp + 16 * C::ROWB + tr_off[0][db], dbp + 16 * C::ROWB + tr_off[1][db]);
-        dvacc[db] = T::mfma(a1, p1, dvacc[db]);
+        dvacc[db] = T::mfma(dof[db][0], p0, dvacc[db]);
+        dvacc[db] = T::mfma(dof[db][1], p1, dvacc[db]);
       }
 #pragma unroll
       for (int db = 0; db < C::DB; ++db) {
-        vec8 a0 = lds_read_tr_frag<T>(qbp + tr_off[0][db], qbp + tr_off[1][db]);
-        dkacc[db] = T::mfma(a0, s0, dkacc[db]);
-        vec8 a1 = lds_read_tr_frag<T>(qbp + 16 * C::ROWB + tr_off[0][db], qbp + 16 * C::ROWB + tr_off[1][db]);
-        dkacc[db] = T::mfma(a1, s1, dkacc[db]);
+        dkacc[db] = T::mfma(qtf[db][0], s0, dkacc[db]);
+        dkacc[db] = T::mfma(qtf[db][1], s1, dkacc[db]);
       }
+      FA_STAMP(3);  // dV and dK MFMAs
+#ifdef FA_STAMPS
+      ++nblk_;
+#endif
     };
 
     auto step_full = [&](int t, auto buf_tag) __attribute__((always_inline)) {
@@ -229,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       const bool more = t + 1 < ntiles;
 #ifndef FA_DMA_SPREAD
       if (more) fetch_tile(t + 1, BUF ^ 1);
+      FA_STAMP(0);  // DMA issue
       auto none = [&](int) __attribute__((always_inline)) {};
       q_block(BUF, 0, 0, std::false_type{}, none);
       q_block(BUF, 1, 0, std::false_type{}, none);
@@ -237,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       q_block(BUF, 1, 0, std::false_type{}, [&](int k) __attribute__((always_inline)) { if (more) fetch_piece(t + 1, BUF ^ 1, 2 + k); });
 #endif
       commit_tile(t + 1, BUF ^ 1, more);
+      FA_STAMP(4);  // vmcnt(0) + row constants + barrier
     };
     auto step_masked = [&](int t) __attribute__((always_inline)) {
       const int buf = t & 1;
@@ -254,6 +291,9 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     using B1 = std::integral_constant<int, 1>;
 
     commit_tile(t_start, t_start & 1, t_start < ntiles);  // first tile landed (and K/V fragments)
+#ifdef FA_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
 
     int t = t_start;
     const int t_masked_end = min(ntiles, t_full);
@@ -272,6 +312,13 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * C::ROWB, lane);
     store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * C::ROWB, lane);
   }  // pass
+#ifdef FA_STAMPS
+  if (p.dbg && lane == 0) {
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+    for (int i = 0; i < 6; ++i) d[i] = seg[i];
+    d[8] = nblk_;
+  }
+#endif
 }
 
 template <typename T, bool CAUSAL>

@@ -244,17 +244,29 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     f32x16 s0[2], s1[2];
     vec8 p0[2][2], p1[2][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s0[b][i] = 0.f;
         s1[b][i] = 0.f;
       }
+    // K fragments two reads ahead of their MFMA pair, order pinned: left alone, hipcc issues each
+    // ds_read right before its consumers and exposes the LDS latency eight times per tile.
+    {
+      constexpr int NF = 2 * C::KS;  // fragment f: key block f / KS, k-step f % KS
+      vec8 kfr[NF];
+      auto kread = [&](int f) __attribute__((always_inline)) {
+        kfr[f] = as_vec8<T>(lds_read16(kt + k_off[f % C::KS] + (f / C::KS) * 32 * C::ROWB));
+      };
+      kread(0);
+      kread(1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
-        s0[b] = T::mfma(a, qf[0][ks], s0[b]);
-        s1[b] = T::mfma(a, qf[1][ks], s1[b]);
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) kread(f + 2);
+        s0[f / C::KS] = T::mfma(kfr[f], qf[0][f % C::KS], s0[f / C::KS]);
+        s1[f / C::KS] = T::mfma(kfr[f], qf[1][f % C::KS], s1[f / C::KS]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     FA_STAMP(1);  // S^T MFMAs
@@ -264,17 +276,23 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     probs(J0{}, s0, p0);
     probs(J1{}, s1, p1);
     FA_STAMP(3);  // exp / sum / pack
+    // V^T fragments: same two-ahead pipeline (fragment f: key block f/4, d block (f/2)%2, k-step f%2)
+    {
+      constexpr int NF = 2 * C::DB * 2;
+      vec8 vfr[NF];
+      auto vread = [&](int f) __attribute__((always_inline)) {
+        const FA_LDS char* base = vt + (f / (2 * C::DB)) * 32 * C::ROWB + (f % 2) * 16 * C::ROWB;
+        const int db = (f / 2) % C::DB;
+        vfr[f] = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
+      };
+      vread(0);
+      vread(1);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const FA_LDS char* base = vt + b * 32 * C::ROWB;
-#pragma unroll
-      for (int db = 0; db < C::DB; ++db) {
-        vec8 a0 = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
-        oacc[0][db] = T::mfma(a0, p0[b][0], oacc[0][db]);
-        oacc[1][db] = T::mfma(a0, p1[b][0], oacc[1][db]);
-        vec8 a1 = lds_read_tr_frag<T>(base + 16 * C::ROWB + v_off[0][db], base + 16 * C::ROWB + v_off[1][db]);
-        oacc[0][db] = T::mfma(a1, p0[b][1], oacc[0][db]);
-        oacc[1][db] = T::mfma(a1, p1[b][1], oacc[1][db]);
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) vread(f + 2);
+        const int b = f / (2 * C::DB), db = (f / 2) % C::DB, ks = f % 2;
+        oacc[0][db] = T::mfma(vfr[f], p0[b][ks], oacc[0][db]);
+        oacc[1][db] = T::mfma(vfr[f], p1[b][ks], oacc[1][db]);
       }
     }
   };

@@ -30,6 +30,7 @@ struct BwdParams {
   int B, H, Sq, Sk;
   float scale;
   int n_tiles;      // filled by the launcher
+  void* dbg;        // diagnostic builds (-DFA_STAMPS) only
 };
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s);

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-segment cycle shares of a -DFA_STAMPS build of the dK/dV kernel (diagnostic only)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flashattention-from-scratch-with-triton_amd"))
+import torch
+import _mi355fa as host
+lib = ctypes.CDLL(os.path.join(ROOT, "ab/stamps.so"))
+for name, (res, args) in host.SIGNATURES.items():
+    fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
+lib.fa_debug_set_buffer.argtypes = [ctypes.c_void_p]
+causal = "--non-causal" not in sys.argv
+B, H, S, D = 4, 32, 4096, 64
+torch.manual_seed(0)
+Q, K, V, dO = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(4))
+O = torch.empty_like(Q); LSE = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
+dQ, dK, dV, delta = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty_like(LSE)
+st = torch.cuda.current_stream().cuda_stream
+P = lambda t: t.data_ptr()
+c, sc = int(causal), D ** -0.5
+lib.fa_fwd(P(Q), P(K), P(V), P(O), P(LSE), B, H, S, S, D, 1, c, sc, st)
+lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, 1, c, sc, st)
+nblk = (S // 128) * B * H
+dbg = torch.zeros(nblk * 4 * 12, dtype=torch.int64, device="cuda")
+for i in range(4):
+    lib.fa_debug_set_buffer(dbg.data_ptr() if i == 3 else None)
+    assert lib.fa_bwd_dkv(P(Q), P(K), P(V), P(dO), P(LSE), P(delta), P(dK), P(dV), B, H, S, S, D, 1, c, sc, st) == 0
+torch.cuda.synchronize()
+d = dbg.cpu().view(nblk, 4, 12).double()
+names = ["DMA issue (per tile)", "reads + S,dP MFMA", "tr reads + VALU", "dV,dK MFMA", "commit+barrier (per tile)"]
+blocks = d[:, :, 8].sum()
+tot = d[:, :, :5].sum()
+print("query blocks per wave (mean): %.1f; total stamped cycles per block: %.0f" % (d[:, :, 8].mean(), tot / blocks))
+for i, n in enumerate(names):
+    print("  %-28s %5.1f%%  %7.0f cycles per 32x32 block" % (n, 100 * d[:, :, i].sum() / tot, d[:, :, i].sum() / blocks))
