@@ -3,9 +3,9 @@
 // Same maths and rounding points as fa_bwd_dkv.hip (reference kernel
 // code/_flash_attention_kernel_optimized.py:292-386; runs after the dQ kernel and reads its delta).
 // What changes against the first-generation kernel:
-//   * Q and dO tiles (64 query rows) go L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), double
+//   * Q and dO tiles (128 query rows) go L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), double
 //     buffered: the copy of tile t+1 is issued before tile t is computed and retired (vmcnt(0)) after
-//     it -- no staging VGPRs and no ds_write pass for the 16 KiB of tile data; only the 2 x 64 row
+//     it -- no staging VGPRs and no ds_write pass for the tile data; only the 2 x 128 row
 //     constants (-LSE*log2e, -delta) pass through a register to be pre-scaled once per workgroup;
 //   * the loop is unrolled by two so that every LDS address is base register + immediate;
 //   * causal: a workgroup takes the key-tile PAIR (i, nk-1-i), so all workgroups stream the same
@@ -20,15 +20,20 @@
 
 namespace fa {
 
+#ifndef FA_DKV_BQ
+#define FA_DKV_BQ 128  // query rows per LDS tile
+#endif
+
 struct Dkv2Cfg {
   static constexpr int D = 64;
-  static constexpr int BK = 128, BQ = 64, NT = 256, NW = 4;
+  static constexpr int BK = 128, BQ = FA_DKV_BQ, NT = 256, NW = 4;
+  static constexpr int QB = BQ / 32;                       // 32-row query blocks per tile
   static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
-  static constexpr int TILE_BYTES = BQ * ROWB;             // 8 KiB per matrix
+  static constexpr int TILE_BYTES = BQ * ROWB;
   static constexpr int DO_BASE = 2 * TILE_BYTES;           // Q[2], then dO[2]
   static constexpr int ROWC_OFF = 4 * TILE_BYTES;          // then row constants: nl[64], nd[64] per buffer
   static constexpr int ROWC_BYTES = 2 * BQ * 4;
-  static constexpr int LDS_BYTES = 4 * TILE_BYTES + 2 * ROWC_BYTES;  // 33 KiB
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES + 2 * ROWC_BYTES;  // 66 KiB at BQ = 128
   static constexpr int DMA_PER_MAT = TILE_BYTES / (NW * 1024);
 };
 
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   int dma_src[C::DMA_PER_MAT];
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
-    const int row = 16 * wave + 8 * i + (lane >> 3);
+    const int row = (C::BQ / C::NW) * wave + 8 * i + (lane >> 3);
     dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane & 7) * 16;
   }
   int row_off[C::KS];
@@ -122,30 +127,12 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       const int soff = t * C::TILE_BYTES;
 #pragma unroll
       for (int i = 0; i < C::DMA_PER_MAT; ++i) {
-        const int dst = buf * C::TILE_BYTES + (16 * wave + 8 * i) * C::ROWB;
+        const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + 8 * i) * C::ROWB;
         dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
         dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i], soff);
       }
-      if (wave == 0) rc = buf_load_f32(rl, (t * C::BQ + lane) * 4);
-      else if (wave == 1) rc = buf_load_f32(rd, (t * C::BQ + lane) * 4);
-    };
-    // the same, cut in four pieces so that the issue of each 1-KiB DMA can hide behind MFMAs
-    auto fetch_piece = [&](int t, int buf, int piece) __attribute__((always_inline)) {
-#ifdef FA_ABLATE_DMA
-      if (t > t_start + 1) return;
-#endif
-      const int soff = t * C::TILE_BYTES;
-      const int i = piece & 1;
-      const int dst = buf * C::TILE_BYTES + (16 * wave + 8 * i) * C::ROWB;
-      if (piece < 2) {
-        dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
-      } else {
-        dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i], soff);
-      }
-      if (piece == 3) {
-        if (wave == 0) rc = buf_load_f32(rl, (t * C::BQ + lane) * 4);
-        else if (wave == 1) rc = buf_load_f32(rd, (t * C::BQ + lane) * 4);
-      }
+      if (tid < C::BQ) rc = buf_load_f32(rl, (t * C::BQ + tid) * 4);                  // waves 0 .. BQ/64-1: LSE rows
+      else if (tid < 2 * C::BQ) rc = buf_load_f32(rd, (t * C::BQ + tid - C::BQ) * 4);  // next BQ/64 waves: delta rows
     };
     // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet
     auto commit_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
@@ -154,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       if (fetched) {
         FA_LDS float* rcp = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
         // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
-        if (wave == 0) rcp[lane] = (t * C::BQ + lane < p.Sq) ? -rc * kLog2e : -INFINITY;
-        else if (wave == 1) rcp[64 + lane] = -rc;
+        if (tid < C::BQ) rcp[tid] = (t * C::BQ + tid < p.Sq) ? -rc * kLog2e : -INFINITY;
+        else if (tid < 2 * C::BQ) rcp[tid] = -rc;  // rcp[BQ + row] = -delta
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the ds_write above
 #ifndef FA_ABLATE_BARRIER
@@ -183,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       }
 
     // one 32-row query block of the tile in buffer `buf`
-    auto q_block = [&](int buf, int b, int qb0, auto masked_tag, auto&& hook) __attribute__((always_inline)) {
+    auto q_block = [&](int buf, int b, int qb0, auto masked_tag) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked_tag)::value;
       const FA_LDS char* qbp = smem + buf * C::TILE_BYTES + b * 32 * C::ROWB;
       const FA_LDS char* dbp = smem + C::DO_BASE + buf * C::TILE_BYTES + b * 32 * C::ROWB;
@@ -192,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // per-register row constants: reg i <-> row (i&3) + 8(i>>2) + 4h
         const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * g + 4 * h) * 4);
-        const f32x4 d = *(const FA_LDS f32x4*)(rcp + (64 + 32 * b + 8 * g + 4 * h) * 4);
+        const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * g + 4 * h) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           nl[4 * g + j] = a[j];
@@ -206,13 +193,11 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
         vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
         sacc = T::mfma(a, kf[ks], sacc);
       }
-      hook(0);
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(dbp + row_off[ks]));
         pacc = T::mfma(a, vf[ks], pacc);
       }
-      hook(1);
       FA_STAMP(1);  // row-constant + row-fragment reads, S and dP MFMA chains
       // transposed fragments for dV^T / dK^T: issued BEFORE the exp / dS arithmetic (order pinned) so that
       // their LDS latency is covered by it; left alone hipcc reads each one right before its MFMA
@@ -262,16 +247,10 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     auto step_full = [&](int t, auto buf_tag) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_tag)::value;
       const bool more = t + 1 < ntiles;
-#ifndef FA_DMA_SPREAD
       if (more) fetch_tile(t + 1, BUF ^ 1);
       FA_STAMP(0);  // DMA issue
-      auto none = [&](int) __attribute__((always_inline)) {};
-      q_block(BUF, 0, 0, std::false_type{}, none);
-      q_block(BUF, 1, 0, std::false_type{}, none);
-#else
-      q_block(BUF, 0, 0, std::false_type{}, [&](int k) __attribute__((always_inline)) { if (more) fetch_piece(t + 1, BUF ^ 1, k); });
-      q_block(BUF, 1, 0, std::false_type{}, [&](int k) __attribute__((always_inline)) { if (more) fetch_piece(t + 1, BUF ^ 1, 2 + k); });
-#endif
+#pragma unroll
+      for (int b = 0; b < C::QB; ++b) q_block(BUF, b, 0, std::false_type{});
       commit_tile(t + 1, BUF ^ 1, more);
       FA_STAMP(4);  // vmcnt(0) + row constants + barrier
     };
@@ -280,10 +259,10 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       const bool more = t + 1 < ntiles;
       if (more) fetch_tile(t + 1, buf ^ 1);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < C::QB; ++b) {
         const int qb0 = t * C::BQ + 32 * b;
         if (qb0 < kw0) continue;  // every row of the block is above the diagonal
-        q_block(buf, b, qb0, std::true_type{}, [&](int) __attribute__((always_inline)) {});
+        q_block(buf, b, qb0, std::true_type{});
       }
       commit_tile(t + 1, buf ^ 1, more);
     };
@@ -327,8 +306,11 @@ static hipError_t launch2(const BwdParams& p, hipStream_t s) {
   const int grid = (CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dkv2_kernel<T, CAUSAL>;
   static const int pad = getenv("FA_LDS_PAD") ? atoi(getenv("FA_LDS_PAD")) : 0;  // diagnostic: force 1 workgroup per CU
+  if (C::LDS_BYTES + pad > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + pad);
+    if (e != hipSuccess) return e;
+  }
   if (pad) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + pad);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES + pad, s, p);
     return hipGetLastError();
   }
