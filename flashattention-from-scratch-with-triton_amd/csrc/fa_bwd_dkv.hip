@@ -33,7 +33,7 @@ struct DkvCfg {
   static constexpr int NT = 256;
   static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
   static constexpr int TILE_BYTES = BQ * ROWB;
-  static constexpr int STAGE = (BQ * CPR) / NT;
+  static constexpr int DMA_PER_MAT = TILE_BYTES / (4 * 1024);  // 1-KiB LDS-DMA instructions per wave per matrix
   static constexpr int ROWC_OFF = 4 * TILE_BYTES;           // row constants after Q[2], dO[2]
   static constexpr int ROWC_BYTES = 2 * BQ * 4;             // nl[64], nd[64] per buffer
   static constexpr int LDS_BYTES = 4 * TILE_BYTES + 2 * ROWC_BYTES;
@@ -81,12 +81,13 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   // tiles t >= t_full are entirely below the diagonal for this wave's keys
   const int t_full = CAUSAL ? kw0 / C::BQ + 1 : 0;
 
-  int st_g[C::STAGE], st_l[C::STAGE];
+  // LDS-DMA source offsets (see fa_fwd.hip): wave w fills rows [16w, 16w+16) of each tile
+  constexpr int RPI = 1024 / C::ROWB;
+  int dma_src[C::DMA_PER_MAT];
 #pragma unroll
-  for (int i = 0; i < C::STAGE; ++i) {
-    const int id = tid + C::NT * i, row = id / C::CPR, c = id % C::CPR;
-    st_g[i] = row * C::ROWB + c * 16;
-    st_l[i] = lds_off<D>(row, c);
+  for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+    const int row = 16 * wave + RPI * i + lane / C::CPR;
+    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
   int row_off[C::KS];
 #pragma unroll
@@ -107,14 +108,15 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       dvacc[db][i] = 0.f;
     }
 
-  u32x4 qst[C::STAGE], dst[C::STAGE];
   float cst = 0.f;  // threads 0..63: LSE row, 64..127: delta row
-  auto stage_load = [&](int t) {
-    const int base = t * C::TILE_BYTES;
+  auto stage_load = [&](int t) __attribute__((always_inline)) {
+    const int soff = t * C::TILE_BYTES;
+    const int buf = t & 1;
 #pragma unroll
-    for (int i = 0; i < C::STAGE; ++i) {
-      qst[i] = buf_load16(rq, base + st_g[i]);
-      dst[i] = buf_load16(rdo, base + st_g[i]);
+    for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+      const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
+      dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
+      dma16(rdo, lds_addr_of(smem + 2 * C::TILE_BYTES + dst), dma_src[i], soff);
     }
     if (tid < 64) {
       cst = buf_load_f32(rl, (t * C::BQ + tid) * 4);
@@ -122,16 +124,11 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       cst = buf_load_f32(rd, (t * C::BQ + tid - 64) * 4);
     }
   };
-  auto stage_write = [&](int t) {
-    const int buf = t & 1;
-    FA_LDS char* qd = smem + buf * C::TILE_BYTES;
-    FA_LDS char* dd = smem + (2 + buf) * C::TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < C::STAGE; ++i) {
-      lds_write16(qd + st_l[i], qst[i]);
-      lds_write16(dd + st_l[i], dst[i]);
-    }
-    FA_LDS float* rc = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
+  // tile t (fetched during the previous step) has landed: publish its pre-scaled row constants, then meet
+  auto stage_write = [&](int t) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    FA_LDS float* rc = (FA_LDS float*)(smem + C::ROWC_OFF + (t & 1) * C::ROWC_BYTES);
     if (tid < 64) {
       // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
       rc[tid] = (t * C::BQ + tid < p.Sq) ? -cst * kLog2e : -INFINITY;
@@ -140,7 +137,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
     }
   };
 
-  auto tile = [&](int t, auto masked_tag) {
+  auto tile = [&](int t, auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     const int buf = t & 1;
     const FA_LDS char* qt = smem + buf * C::TILE_BYTES;
@@ -209,9 +206,12 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
     }
   };
 
+  if (p.Sq % C::BQ != 0) {  // a ragged last query tile must not expose uninitialised LDS
+    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    __syncthreads();
+  }
   if (t_start < ntiles) {
     stage_load(t_start);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tile + K/V fragments landed
     stage_write(t_start);
   }
   __syncthreads();

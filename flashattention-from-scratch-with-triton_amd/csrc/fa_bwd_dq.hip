@@ -31,12 +31,12 @@ struct DqCfg {
   static constexpr int BM = 128, BN = 64, NT = 256;
   static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
   static constexpr int TILE_BYTES = BN * ROWB;
-  static constexpr int STAGE = (BN * CPR) / NT;
+  static constexpr int DMA_PER_MAT = TILE_BYTES / (4 * 1024);  // 1-KiB LDS-DMA instructions per wave per matrix
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;
 };
 
 template <int D, typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dq_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
   using C = DqCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -87,12 +87,13 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dq_kernel(BwdPa
   const int ntiles = (kv_end + C::BN - 1) / C::BN;
   const int nfull = CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN;
 
-  int st_g[C::STAGE], st_l[C::STAGE];
+  // LDS-DMA source offsets (see fa_fwd.hip): wave w fills rows [16w, 16w+16) of each tile
+  constexpr int RPI = 1024 / C::ROWB;
+  int dma_src[C::DMA_PER_MAT];
 #pragma unroll
-  for (int i = 0; i < C::STAGE; ++i) {
-    const int id = tid + C::NT * i, row = id / C::CPR, c = id % C::CPR;
-    st_g[i] = row * C::ROWB + c * 16;
-    st_l[i] = lds_off<D>(row, c);
+  for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+    const int row = 16 * wave + RPI * i + lane / C::CPR;
+    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
   int row_off[C::KS];  // A-operand row reads (K rows and V rows)
 #pragma unroll
@@ -110,26 +111,23 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dq_kernel(BwdPa
 #pragma unroll
     for (int i = 0; i < 16; ++i) dqacc[db][i] = 0.f;
 
-  u32x4 kst[C::STAGE], vst[C::STAGE];
-  auto stage_load = [&](int t) {
-    const int base = t * C::TILE_BYTES;
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int soff = t * C::TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < C::STAGE; ++i) {
-      kst[i] = buf_load16(rk, base + st_g[i]);
-      vst[i] = buf_load16(rv, base + st_g[i]);
+    for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+      const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
+      dma16(rk, lds_addr_of(smem + dst), dma_src[i], soff);
+      dma16(rv, lds_addr_of(smem + 2 * C::TILE_BYTES + dst), dma_src[i], soff);
     }
   };
-  auto stage_write = [&](int buf) {
-    FA_LDS char* kd = smem + buf * C::TILE_BYTES;
-    FA_LDS char* vd = smem + (2 + buf) * C::TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < C::STAGE; ++i) {
-      lds_write16(kd + st_l[i], kst[i]);
-      lds_write16(vd + st_l[i], vst[i]);
-    }
+  auto tile_sync = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
-  auto tile = [&](int t, auto masked_tag) {
+  auto tile = [&](int t, auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
     const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
@@ -178,24 +176,22 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dq_kernel(BwdPa
     }
   };
 
-  stage_load(0);
-  stage_write(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __syncthreads();
-  int t = 0;
-  for (; t < nfull; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) stage_load(t + 1);
-    tile(t, std::false_type{});
-    if (more) stage_write((t + 1) & 1);
+  if (p.Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS
+    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
     __syncthreads();
   }
+  dma_tile(0, 0);
+  tile_sync();
+  int t = 0;
+  for (; t < nfull; ++t) {
+    if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
+    tile(t, std::false_type{});
+    tile_sync();
+  }
   for (; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) stage_load(t + 1);
+    if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
     tile(t, std::true_type{});
-    if (more) stage_write((t + 1) & 1);
-    __syncthreads();
+    tile_sync();
   }
 
   store_tile_rows<D, T>(dqacc, p.scale, smem + wave * 32 * C::ROWB, rdq, qw0 * C::ROWB, lane);

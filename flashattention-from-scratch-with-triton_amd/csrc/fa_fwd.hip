@@ -33,7 +33,7 @@ struct FwdCfg {
   static constexpr int KS = D / 16;        // k-steps of S^T = K Q^T
   static constexpr int DB = D / 32;        // 32-wide d blocks of O^T
   static constexpr int TILE_BYTES = BN * ROWB;
-  static constexpr int STAGE = (BN * CPR) / NT;  // 16-byte chunks per thread per matrix
+  static constexpr int DMA_PER_MAT = TILE_BYTES / (4 * 1024);  // 1-KiB LDS-DMA instructions per wave per matrix
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2], V[2]
 };
 
@@ -57,7 +57,7 @@ struct FwdCfg {
 constexpr float kDeferLog2 = 6.0f;
 
 template <int D, typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, (D == 64 ? 3 : 1)) void fa_fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParams p) {
   using C = FwdCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -99,12 +99,15 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 1)) void fa_fwd_kernel(FwdParam
   const int nfull = CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN;
 
   // ---- staging addresses ----
-  int st_g[C::STAGE], st_l[C::STAGE];
+  // ---- LDS-DMA: wave w fills rows [16w, 16w+16) of each K / V tile, 1 KiB (1024 / ROWB rows) per instruction;
+  // lane p of instruction i lands on LDS row 16w + i*RPI + p/CPR, physical chunk p%CPR, so it fetches the
+  // logical chunk swz(row, p%CPR) of that row (swizzle on the SOURCE address, the destination is wave-linear)
+  constexpr int RPI = 1024 / C::ROWB;  // rows per DMA instruction
+  int dma_src[C::DMA_PER_MAT];
 #pragma unroll
-  for (int i = 0; i < C::STAGE; ++i) {
-    const int id = tid + C::NT * i, row = id / C::CPR, c = id % C::CPR;
-    st_g[i] = row * C::ROWB + c * 16;
-    st_l[i] = lds_off<D>(row, c);
+  for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+    const int row = 16 * wave + RPI * i + lane / C::CPR;
+    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
   // ---- fragment read addresses (loop invariant) ----
   int k_off[C::KS];
@@ -126,29 +129,23 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 1)) void fa_fwd_kernel(FwdParam
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
 
-  u32x4 kst[C::STAGE], vst[C::STAGE];
-  auto stage_load = [&](int t) {
-    const int base = t * C::TILE_BYTES;
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int soff = t * C::TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < C::STAGE; ++i) {
-      kst[i] = buf_load16(rk, base + st_g[i]);
-      vst[i] = buf_load16(rv, base + st_g[i]);
+    for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+      const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
+      dma16(rk, lds_addr_of(smem + dst), dma_src[i], soff);
+      dma16(rv, lds_addr_of(smem + 2 * C::TILE_BYTES + dst), dma_src[i], soff);
     }
   };
-  auto stage_write = [&](int buf) {
-    FA_LDS char* kd = smem + buf * C::TILE_BYTES;
-    FA_LDS char* vd = smem + (2 + buf) * C::TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < C::STAGE; ++i) {
-      lds_write16(kd + st_l[i], kst[i]);
-      lds_write16(vd + st_l[i], vst[i]);
-    }
+  // the tile fetched during this step has landed (vmcnt(0)); every wave is done with the current one
+  auto tile_sync = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
-#ifdef FA_STAMPS
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = 0;
-#endif
   // One 64-key tile for this wave.  MASKED = false: every key visible to every row.
   // BUF = 0/1: LDS buffer known at compile time (offsets fold into the ds_read immediates);
   // BUF = -1: taken from t at run time (the few masked tiles).
@@ -249,24 +246,24 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 1)) void fa_fwd_kernel(FwdParam
   auto iter = [&](int t, auto buf_tag, auto masked_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
     const bool more = t + 1 < ntiles;
-    if (more) stage_load(t + 1);
+    if (more) dma_tile(t + 1, BUF >= 0 ? (BUF ^ 1) : ((t + 1) & 1));
     FA_STAMP(0);  // issue of the prefetch
     tile(t, buf_tag, masked_tag);
     FA_STAMP(3);  // P pack + PV MFMAs
-    if (more) stage_write(BUF >= 0 ? (BUF ^ 1) : ((t + 1) & 1));
-    FA_STAMP(4);  // vmcnt wait + ds_write
-    __syncthreads();
-    FA_STAMP(5);  // barrier
+    tile_sync();
+    FA_STAMP(5);  // vmcnt + barrier
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   using BR = std::integral_constant<int, -1>;
 
   // ---- main loop: one barrier per tile; every wave runs exactly ntiles iterations ----
-  stage_load(0);
-  stage_write(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q fragments landed, nothing pending enters the loop
-  __syncthreads();
+  if (p.Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS (out-of-range DMA may not write)
+    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    __syncthreads();
+  }
+  dma_tile(0, 0);
+  tile_sync();  // tile 0 and the Q fragments landed
 #ifdef FA_STAMPS
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
   const unsigned long long begin_ = last_;
