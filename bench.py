@@ -153,7 +153,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            traffic = json.load(open(tpath)).get(dom, {}).get("bytes")  # HBM bytes per launch, PMC (profiles/)
         except Exception:
             traffic = None
     roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": PEAK_TFLOPS,
