@@ -5,6 +5,10 @@
 #include "../../include/mi355fa.h"
 #include "fa_kernels.h"
 
+namespace fa {
+int g_force_fwd = 0, g_force_dq = 0, g_force_dkv = 0;  // 0 = selection rule of fa_kernels.h
+}
+
 namespace {
 
 thread_local char g_err[256] = "";
@@ -41,6 +45,13 @@ extern "C" {
 
 int fa_abi_version(void) { return MI355FA_ABI_VERSION; }
 
+// Not part of the public header: pin the schedule family per kernel (0 = automatic rule); tests and A/B tools.
+void fa_debug_force_impl(int fwd, int dq, int dkv) {
+  fa::g_force_fwd = fwd;
+  fa::g_force_dq = dq;
+  fa::g_force_dkv = dkv;
+}
+
 // Not part of the public header: diagnostic hook used by tools/stamps.py with -DFA_STAMPS builds.
 void fa_debug_set_buffer(void* p) { g_dbg = p; }
 
@@ -56,7 +67,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int
   if (int rc = check_common("fa_fwd", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd");
-  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg};
+  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg, 0};
   hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_fwd launch");
   return 0;
@@ -69,7 +80,7 @@ int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const 
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
       misaligned(dq) || misaligned(delta))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq");
-  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg};
+  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
   hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
   return 0;
@@ -83,7 +94,7 @@ int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, co
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
       misaligned(dk) || misaligned(dv))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv");
-  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg};
+  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
   hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
   return 0;

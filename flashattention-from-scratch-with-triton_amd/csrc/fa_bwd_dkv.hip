@@ -51,11 +51,18 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
+  // causal: key tile i meets the query tiles from i on, so a workgroup takes the PAIR (i, nk-1-i)
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = w / p.n_tiles;
-  const int kt_idx = w - bh * p.n_tiles;  // causal: low key tiles are the heavy ones and come first
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const int bh = w / per_bh;
+  const int idx = w - bh * per_bh;
+  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int kt_idx = paired ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
   const int k0_wg = kt_idx * C::BK;
   const int kw0 = k0_wg + wave * 32;
+  if (pass) __syncthreads();  // the previous pass staged dK / dV in the tile buffers
 
   const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
   const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
@@ -235,12 +242,13 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   FA_LDS char* stage = smem + wave * 32 * C::ROWB;
   store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * C::ROWB, lane);
   store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * C::ROWB, lane);
+  }  // pass
 }
 
 template <int D, typename T, bool CAUSAL>
 static hipError_t launch(const BwdParams& p, hipStream_t s) {
   using C = DkvCfg<D>;
-  const int grid = p.n_tiles * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dkv_kernel<D, T, CAUSAL>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -254,10 +262,11 @@ hipError_t launch_bwd_dkv_v2(BwdParams p, int dtype, int causal, hipStream_t s);
 hipError_t launch_bwd_dkv_v3(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v3.hip
 
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  static const int impl = getenv("FA_DKV_IMPL") ? atoi(getenv("FA_DKV_IMPL")) : 2;  // 2 = default; 1, 3: other schedules (A/B only)
-  if (D == 64 && impl == 3) return launch_bwd_dkv_v3(p, dtype, causal, s);
-  if (D == 64 && impl == 2) return launch_bwd_dkv_v2(p, dtype, causal, s);
+  const int impl = pick_dkv_impl(g_force_dkv, D, p.Sq);
+  if (impl == 3) return launch_bwd_dkv_v3(p, dtype, causal, s);  // one wave per SIMD, 64 keys per wave: A/B only
+  if (impl == 2) return launch_bwd_dkv_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;
+  p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);

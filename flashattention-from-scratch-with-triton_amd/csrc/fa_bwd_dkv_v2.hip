@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   const int r = lane & 31, h = lane >> 5;
 
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int per_bh = CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (CAUSAL && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
 
   const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
   const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   unsigned long long last_ = 0, nblk_ = 0;
 #endif
   for (int pass = 0; pass < npass; ++pass) {
-    const int kt_idx = CAUSAL ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
+    const int kt_idx = paired ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
     const int k0_wg = kt_idx * C::BK;
     const int kw0 = k0_wg + wave * 32;
     if (pass) __syncthreads();  // previous pass staged dK / dV in the tile buffers
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 template <typename T, bool CAUSAL>
 static hipError_t launch2(const BwdParams& p, hipStream_t s) {
   using C = Dkv2Cfg;
-  const int grid = (CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dkv2_kernel<T, CAUSAL>;
   static const int pad = getenv("FA_LDS_PAD") ? atoi(getenv("FA_LDS_PAD")) : 0;  // diagnostic: force 1 workgroup per CU
   if (C::LDS_BYTES + pad > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
@@ -320,6 +321,7 @@ static hipError_t launch2(const BwdParams& p, hipStream_t s) {
 
 hipError_t launch_bwd_dkv_v2(BwdParams p, int dtype, int causal, hipStream_t s) {
   p.n_tiles = (p.Sk + Dkv2Cfg::BK - 1) / Dkv2Cfg::BK;
+  p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
   if (dtype == 1) return causal ? launch2<BF16, true>(p, s) : launch2<BF16, false>(p, s);
   return causal ? launch2<FP16, true>(p, s) : launch2<FP16, false>(p, s);
 }

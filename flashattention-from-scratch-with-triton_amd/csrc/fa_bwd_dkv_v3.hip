@@ -49,10 +49,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
   const int r = lane & 31, h = lane >> 5;
 
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int per_bh = CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (CAUSAL && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
 
   const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
   const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
   }
 
   for (int pass = 0; pass < npass; ++pass) {
-    const int kt_idx = CAUSAL ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
+    const int kt_idx = paired ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
     const int k0_wg = kt_idx * C::BK;
     const int kw0 = k0_wg + wave * 64;
     if (pass) __syncthreads();  // previous pass staged dK / dV in the tile buffers
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
 template <typename T, bool CAUSAL>
 static hipError_t launch3(const BwdParams& p, hipStream_t s) {
   using C = Dkv3Cfg;
-  const int grid = (CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dkv3_kernel<T, CAUSAL>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();
@@ -274,6 +275,7 @@ static hipError_t launch3(const BwdParams& p, hipStream_t s) {
 
 hipError_t launch_bwd_dkv_v3(BwdParams p, int dtype, int causal, hipStream_t s) {
   p.n_tiles = (p.Sk + Dkv3Cfg::BK - 1) / Dkv3Cfg::BK;
+  p.pair = causal != 0;
   if (dtype == 1) return causal ? launch3<BF16, true>(p, s) : launch3<BF16, false>(p, s);
   return causal ? launch3<FP16, true>(p, s) : launch3<FP16, false>(p, s);
 }

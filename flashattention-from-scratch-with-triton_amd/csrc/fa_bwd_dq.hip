@@ -47,12 +47,18 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
+  // causal: a workgroup takes the query-tile pair (nq-1-i, i) -> equal work everywhere (see fa_fwd.hip)
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = w / p.n_tiles;
-  int qt = w - bh * p.n_tiles;
-  if (CAUSAL) qt = p.n_tiles - 1 - qt;
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const int bh = w / per_bh;
+  const int idx = w - bh * per_bh;
+  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qt = paired ? (pass == 0 ? p.n_tiles - 1 - idx : idx) : (CAUSAL ? p.n_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 32;
+  if (pass) __syncthreads();  // the previous pass staged its dQ tile in the K/V buffers
 
   const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
   const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
@@ -195,12 +201,13 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
   }
 
   store_tile_rows<D, T>(dqacc, p.scale, smem + wave * 32 * C::ROWB, rdq, qw0 * C::ROWB, lane);
+  }  // pass
 }
 
 template <int D, typename T, bool CAUSAL>
 static hipError_t launch(const BwdParams& p, hipStream_t s) {
   using C = DqCfg<D>;
-  const int grid = p.n_tiles * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dq_kernel<D, T, CAUSAL>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -213,9 +220,9 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v2.hip
 
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  static const bool use_v1 = getenv("FA_DQ_V1") != nullptr;  // A/B only
-  if (D == 64 && !use_v1) return launch_bwd_dq_v2(p, dtype, causal, s);
+  if (pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0) == 2) return launch_bwd_dq_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sq + 127) / 128;
+  p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);

@@ -42,12 +42,13 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
 
   // causal: each workgroup takes the query-tile pair (nq-1-i, i) -> equal work everywhere (fa_fwd_v2.hip)
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int per_bh = CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (CAUSAL && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qt = CAUSAL ? (pass == 0 ? p.n_tiles - 1 - idx : idx) : idx;
+  const int qt = paired ? (pass == 0 ? p.n_tiles - 1 - idx : idx) : (CAUSAL ? p.n_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 64;
   if (pass) __syncthreads();  // the previous pass staged its dQ tile in the ring
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
 template <typename T, bool CAUSAL>
 static hipError_t launch2(const BwdParams& p, hipStream_t s) {
   using C = Dq2Cfg;
-  const int grid = (CAUSAL ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dq2_kernel<T, CAUSAL>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();
@@ -265,6 +266,7 @@ static hipError_t launch2(const BwdParams& p, hipStream_t s) {
 
 hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s) {
   p.n_tiles = (p.Sq + Dq2Cfg::BM - 1) / Dq2Cfg::BM;
+  p.pair = causal != 0;
   if (dtype == 1) return causal ? launch2<BF16, true>(p, s) : launch2<BF16, false>(p, s);
   return causal ? launch2<FP16, true>(p, s) : launch2<FP16, false>(p, s);
 }

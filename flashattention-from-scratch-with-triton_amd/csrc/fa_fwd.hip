@@ -37,22 +37,6 @@ struct FwdCfg {
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2], V[2]
 };
 
-// Diagnostic build only (-DFA_STAMPS): per-wave cycle shares of the loop segments, accumulated in
-// SGPRs and written to a side buffer (FwdParams::dbg) that nothing else reads.
-#ifdef FA_STAMPS
-#define FA_STAMP(slot)                                                            \
-  do {                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    unsigned long long now_;                                                      \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    seg[slot] += now_ - last_;                                                    \
-    last_ = now_;                                                                 \
-  } while (0)
-#else
-#define FA_STAMP(slot) do {} while (0)
-#endif
-
 // Online-softmax rescale is deferred until a row max grows by more than 2^kDeferLog2 (see tile()).
 constexpr float kDeferLog2 = 6.0f;
 
@@ -69,12 +53,20 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   const int r = lane & 31, h = lane >> 5;
 
   // ---- which (batch*head, q tile) ----
+  // Work list: non-causal -> one 128-row query tile per workgroup.  Causal -> query tile i streams i+1
+  // K/V tiles, so a workgroup takes the PAIR (nq-1-i, i): every workgroup then does the same work and the
+  // grid is balanced whatever the number of CUs (heavy tile first).
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = w / p.nq_tiles;
-  int qt = w - bh * p.nq_tiles;
-  if (CAUSAL) qt = p.nq_tiles - 1 - qt;  // heaviest tiles first
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
+  const int bh = w / per_bh;
+  const int idx = w - bh * per_bh;
+  const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 32;
+  if (pass) __syncthreads();  // the previous pass staged its O tile in the K/V buffers
 
   const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
   const char* kb = (const char*)p.k + (size_t)bh * p.Sk * C::ROWB;
@@ -199,7 +191,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
       tm1 = __builtin_fmaxf(tm1, sacc[1][i]);
     }
     const float tm = half_max(__builtin_fmaxf(tm0, tm1));
-    FA_STAMP(1);  // S^T MFMAs + row max
     // Deferred rescale: the running max is only raised when some row's tile max exceeds it by
     // more than kDefer (in log2 units), so P stays <= 2^kDefer (exact in fp32, same RELATIVE
     // rounding in 16 bit) and the O-wide multiply is rare.  m = -inf (first tile) always fires.
@@ -224,7 +215,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
         ls[i & 3] += pe;
       }
     l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
-    FA_STAMP(2);  // rescale + exp + row sum
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -247,11 +237,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     constexpr int BUF = decltype(buf_tag)::value;
     const bool more = t + 1 < ntiles;
     if (more) dma_tile(t + 1, BUF >= 0 ? (BUF ^ 1) : ((t + 1) & 1));
-    FA_STAMP(0);  // issue of the prefetch
     tile(t, buf_tag, masked_tag);
-    FA_STAMP(3);  // P pack + PV MFMAs
     tile_sync();
-    FA_STAMP(5);  // vmcnt + barrier
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -264,10 +251,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   }
   dma_tile(0, 0);
   tile_sync();  // tile 0 and the Q fragments landed
-#ifdef FA_STAMPS
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
-  const unsigned long long begin_ = last_;
-#endif
   int t = 0;
   for (; t + 2 <= nfull; t += 2) {  // unmasked tiles, two per trip so that the LDS buffer is a constant
     iter(t, B0{}, std::false_type{});
@@ -280,35 +263,19 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   for (; t < ntiles; ++t) iter(t, BR{}, std::true_type{});
 
   // ---- epilogue ----
-#ifdef FA_STAMPS
-  const unsigned long long loop_end_ = last_;
-#endif
   const float lt = half_sum(l);
   const float inv = 1.0f / lt;
   // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
   store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * C::ROWB, lane);
   if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * p.scale + __builtin_logf(lt));
-#ifdef FA_STAMPS
-  if (p.dbg && lane == 0) {
-    unsigned long long end_;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(end_)::"memory");
-    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-    for (int i = 0; i < 6; ++i) d[i] = seg[i];
-    d[6] = loop_end_ - begin_;   // loop
-    d[7] = end_ - loop_end_;     // epilogue
-    d[8] = ntiles;
-    d[9] = nfull;
-    d[10] = begin_;
-    d[11] = end_;
-  }
-#endif
+  }  // pass
 }
 
 // ---- host launcher ----------------------------------------------------------
 template <int D, typename T, bool CAUSAL>
 static hipError_t launch(const FwdParams& p, hipStream_t s) {
   using C = FwdCfg<D>;
-  const int grid = p.nq_tiles * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
   auto kern = fa_fwd_kernel<D, T, CAUSAL>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -321,10 +288,9 @@ static hipError_t launch(const FwdParams& p, hipStream_t s) {
 hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v2.hip
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  // D = 64 runs the 256-row / LDS-DMA schedule; FA_FWD_V1=1 selects the first-generation kernel (A/B only)
-  static const bool use_v1 = getenv("FA_FWD_V1") != nullptr;
-  if (D == 64 && !use_v1) return launch_fwd_v2(p, dtype, causal, s);
+  if (pick_fwd_dq_impl(g_force_fwd, D, p.B, p.H, p.Sq, causal != 0) == 2) return launch_fwd_v2(p, dtype, causal, s);
   p.nq_tiles = (p.Sq + 127) / 128;
+  p.pair = want_pairs(causal != 0, p.nq_tiles, (long)p.B * p.H);
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);

@@ -68,12 +68,13 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   // K/V steps, so each workgroup takes the PAIR (nq-1-i, i): every workgroup then streams nq+1 steps
   // and the grid is perfectly balanced (heavy tile first).
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int per_bh = CAUSAL ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (CAUSAL && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
+  const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qt = CAUSAL ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : idx;
+  const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 64;
   if (pass) __syncthreads();  // the previous pass staged its O tile in the ring
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
 template <typename T, bool CAUSAL>
 static hipError_t launch2(const FwdParams& p, hipStream_t s) {
   using C = Fwd2Cfg;
-  const int grid = (CAUSAL ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
+  const int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
   auto kern = fa_fwd2_kernel<T, CAUSAL>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();
@@ -425,6 +426,7 @@ static hipError_t launch2(const FwdParams& p, hipStream_t s) {
 
 hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s) {
   p.nq_tiles = (p.Sq + Fwd2Cfg::BM - 1) / Fwd2Cfg::BM;
+  p.pair = causal != 0;
   if (dtype == 1) return causal ? launch2<BF16, true>(p, s) : launch2<BF16, false>(p, s);
   return causal ? launch2<FP16, true>(p, s) : launch2<FP16, false>(p, s);
 }

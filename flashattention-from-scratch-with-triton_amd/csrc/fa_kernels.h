@@ -14,6 +14,7 @@ struct FwdParams {
   float scale;
   int nq_tiles;  // filled by the launcher
   void* dbg;     // diagnostic builds (-DFA_STAMPS) only: cycle-stamp buffer, else unused
+  int pair;      // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
 };
 
 struct BwdParams {
@@ -31,7 +32,34 @@ struct BwdParams {
   float scale;
   int n_tiles;      // filled by the launcher
   void* dbg;        // diagnostic builds (-DFA_STAMPS) only
+  int pair;         // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
 };
+
+// ---- schedule selection (the counterpart of the reference's autotune key (S_q, S_k, D, is_causal),
+// K:18-32): a static rule per kernel instead of a run-time search.  Two schedule families exist for D = 64:
+//   1 = 128-row (128-key) workgroups, 32 rows per wave, up to 3 waves per SIMD  (also the only D = 128 path)
+//   2 = 256-row workgroups, 64 rows per wave sharing every K/V fragment (forward, dQ); 128-row Q/dO tiles (dK/dV)
+// Measured on MI355X (profiles/r01_schedule_selection.txt): family 1 wins on small grids and on causal
+// forward / dQ; family 2 wins on large non-causal grids and for dK/dV at S_q >= 2048.
+// fa_debug_force_impl() (not in the public header) overrides the rule for tests and A/B runs; 0 = rule.
+extern int g_force_fwd, g_force_dq, g_force_dkv;
+inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal) {
+  if (D != 64) return 1;
+  if (forced) return forced;
+  const long tiles256 = (Sq + 255) / 256;
+  const long wgs2 = (long)B * H * (causal ? (tiles256 + 1) / 2 : tiles256);
+  return (!causal && wgs2 >= 512) ? 2 : 1;
+}
+inline int pick_dkv_impl(int forced, int D, int Sq) {
+  if (D != 64) return 1;
+  if (forced) return forced;
+  return Sq >= 2048 ? 2 : 1;
+}
+
+// Causal tile pairing equalises the work per workgroup but halves the number of workgroups: worth it as
+// long as the paired grid still gives every one of the 256 CUs a workgroup (measured: B4 H8 S2048 -> 256
+// pairs: 0.030 ms paired vs 0.038 ms unpaired; S512 -> 64 pairs: 0.014 vs 0.010 ms).
+inline int want_pairs(bool causal, long tiles, long bh) { return causal && ((tiles + 1) / 2) * bh >= 256; }
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s);
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s);

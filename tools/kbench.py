@@ -35,6 +35,7 @@ ap.add_argument("--dim", type=int, default=64)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--kernels", default="fwd,dq,dkv")
 ap.add_argument("--non-causal", action="store_true")
+ap.add_argument("--impl", default="", help="force schedule family per kernel: fwd,dq,dkv (0 = rule), e.g. 1,1,2")
 a = ap.parse_args()
 
 
@@ -43,6 +44,8 @@ def load(path):
     for name, (res, args) in host.SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    if a.impl and hasattr(lib, "fa_debug_force_impl"):
+        lib.fa_debug_force_impl(*[int(x) for x in a.impl.split(",")])
     return lib
 
 
