@@ -39,6 +39,8 @@ struct FwdCfg {
 
 // Online-softmax rescale is deferred until a row max grows by more than 2^kDeferLog2 (see tile()).
 constexpr float kDeferLog2 = 6.0f;
+// Lazy running max: largest partial row sum accepted without recomputing the true max (see tile_lazy).
+constexpr float kLazySumMax = 8192.0f;
 
 template <int D, typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParams p) {
@@ -232,6 +234,55 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     }
   };
 
+  // Unmasked tile with a LAZY running max: exponentiate against the stale row max -- no max reduction, no
+  // cross-half exchange, no rescale test.  All p >= 0, so a lane's partial row sum bounds every p it holds: if
+  // no partial sum exceeds kLazySumMax nothing can overflow (fp32 sums, 16-bit P fragments) and the stale max
+  // is exactly as good as the true one (softmax is shift invariant).  Otherwise (always the first tile: m = -inf
+  // gives p = +inf; afterwards only if scores jump by more than ~2^8) NOTHING has been committed: return false
+  // and the caller redoes the tile on the exact path.
+  auto tile_lazy = [&](int t) __attribute__((always_inline)) -> bool {
+    const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[b][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
+        sacc[b] = T::mfma(a, qf[ks], sacc[b]);
+      }
+    }
+    const float mc = m * c2;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][i], c2, -mc));
+        sacc[b][i] = pe;
+        ls[i & 3] += pe;
+      }
+    const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    if (__builtin_amdgcn_ballot_w64(!(lsum <= kLazySumMax)) != 0) return false;
+    l += lsum;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const vec8 pf0 = pack8<T, 0>(sacc[b]);
+      const vec8 pf1 = pack8<T, 1>(sacc[b]);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        const FA_LDS char* base = vt + b * 32 * C::ROWB;
+        vec8 a0 = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
+        oacc[db] = T::mfma(a0, pf0, oacc[db]);
+        vec8 a1 = lds_read_tr_frag<T>(base + 16 * C::ROWB + v_off[0][db], base + 16 * C::ROWB + v_off[1][db]);
+        oacc[db] = T::mfma(a1, pf1, oacc[db]);
+      }
+    }
+    return true;
+  };
+
   // one loop iteration: prefetch tile t+1 to registers, compute tile t, park t+1 in the other buffer
   auto iter = [&](int t, auto buf_tag, auto masked_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
@@ -251,14 +302,25 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   }
   dma_tile(0, 0);
   tile_sync();  // tile 0 and the Q fragments landed
+  // Unmasked tiles: one exact tile (the first one, or the one a lazy tile bailed out of -- its prefetch is
+  // then already issued), followed by lazy tiles until one bails out.  Separate loops on purpose: bodies that
+  // merge control flow get their accumulators copied at every join.
   int t = 0;
-  for (; t + 2 <= nfull; t += 2) {  // unmasked tiles, two per trip so that the LDS buffer is a constant
-    iter(t, B0{}, std::false_type{});
-    iter(t + 1, B1{}, std::false_type{});
-  }
-  if (t < nfull) {
-    iter(t, B0{}, std::false_type{});
+  bool prefetched = false;
+  while (t < nfull) {
+    if (!prefetched && t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
+    tile(t, BR{}, std::false_type{});
+    tile_sync();
     ++t;
+    prefetched = false;
+    for (; t < nfull; ++t) {
+      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
+      if (!tile_lazy(t)) {
+        prefetched = true;
+        break;
+      }
+      tile_sync();
+    }
   }
   for (; t < ntiles; ++t) iter(t, BR{}, std::true_type{});
 

@@ -98,6 +98,11 @@ def bench(B, H, N, D, causal, dtype, rep=20):
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
+    for a in sys.argv:
+        if a.startswith("--impl="):  # force the schedule family per kernel: --impl=fwd,dq,dkv
+            import ctypes
+            M._fa.lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+            M._fa.lib.fa_debug_force_impl(*[int(x) for x in a.split("=")[1].split(",")])
     print("device:", torch.cuda.get_device_name(0), flush=True)
     ok = True
     bf, hf = torch.bfloat16, torch.float16

@@ -159,6 +159,9 @@ def test_rescale_branch_is_exercised_by_a_late_spike(impl):
     Q, K, V, dO = rand_inputs(B, H, S, S, D, F16, seed=9)
     K[0, 0, 517] = (Q[0, 0, 600].float() * 0.9).half()     # huge score for row 600 at key 517 (tile 8)
     K[0, 0, 70] = (Q[0, 0, 100].float() * 0.7).half()
+    # a jump of > 2^13 in one step: forces the lazy-max forward tile to bail out to the exact path late
+    # (raw score 1.7 * |q|^2 ~ 110 -> exp2(110 * 0.18) ~ 2^20 against the stale max)
+    K[0, 0, 450] = (Q[0, 0, 520].float() * 1.7).half()
     for causal in (False, True):
         gt = fo.attention_fp64(Q, K, V, dO, causal)
         r = run_gpu_raw(Q, K, V, dO, causal)
