@@ -245,13 +245,108 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 #endif
     };
 
+    // ---- unmasked tile, hand-ordered: software pipeline over the tile's query blocks -------------------------
+    // A block is 16 MFMA "slots": 0-3 S = Q K^T, 4-7 dP = dO V^T (block b), 8-11 dV^T += dO^T P, 12-15
+    // dK^T += Q^T dS (block b-1).  Every slot is one group "MFMA, the LDS read of the operand FOUR slots ahead,
+    // a few VALU ops of the other block", closed by sched_barrier(0): the compiler keeps exactly this order (it
+    // still allocates registers, counts waits and pads hazards).  Left alone, hipcc reads each operand one or two
+    // MFMAs before its use and every wave then sits on the LDS latency sixteen times per block; here the reads
+    // are ~140 cycles ahead and the VALU work hides in the issue cycles the MFMAs leave free.
+    auto tile_pipelined = [&](auto buf_tag) __attribute__((always_inline)) {
+      constexpr int BUF = decltype(buf_tag)::value;
+      const FA_LDS char* qt = smem + BUF * C::TILE_BYTES;
+      const FA_LDS char* dt = smem + C::DO_BASE + BUF * C::TILE_BYTES;
+      const FA_LDS char* rcp = smem + C::ROWC_OFF + BUF * C::ROWC_BYTES;
+      // operand fragment of slot s of block b (block index QB = the drain pass: only slots 8..15 exist)
+      auto frag = [&](int b, int s) __attribute__((always_inline)) -> vec8 {
+        if (s < 8) {  // row fragments of block b: Q rows (k-steps 0..3), then dO rows
+          const FA_LDS char* base = (s < 4 ? qt : dt) + b * 32 * C::ROWB;
+          return as_vec8<T>(lds_read16(base + row_off[s & 3]));
+        }
+        // transposed fragments of block b-1: dO^T (d block 0: k-steps 0,1; d block 1: 0,1), then Q^T
+        const int n = s - 8, db = (n >> 1) & 1;
+        const FA_LDS char* base = (n < 4 ? dt : qt) + (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
+        return lds_read_tr_frag<T>(base + tr_off[0][db], base + tr_off[1][db]);
+      };
+      f32x16 xP, dP_;               // previous block: exponent argument s*c2 - LSE*log2e, and dP - delta
+      vec8 pk[2], sk[2];            // previous block: packed P and dS fragments (k-steps 0, 1)
+      vec8 fr[4];                   // operand ring, four slots deep
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fr[s] = frag(0, s);
+#pragma unroll
+      for (int b = 0; b <= C::QB; ++b) {
+        const bool cur = b < C::QB;   // block b exists: slots 0..7
+        const bool prev = b > 0;      // block b-1 exists: slots 8..15 and its VALU work
+        f32x16 nl, pacc, sacc;
+        if (cur) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * g + 4 * h) * 4);
+            const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * g + 4 * h) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              nl[4 * g + j] = a[j];
+              pacc[4 * g + j] = d[j];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const bool active = s < 8 ? cur : prev;
+          if (active) {
+            const vec8 a = fr[s & 3];
+            if (s < 4) sacc = T::mfma(a, kf[s], sacc);
+            else if (s < 8) pacc = T::mfma(a, vf[s - 4], pacc);
+            else if (s < 12) dvacc[((s - 8) >> 1) & 1] = T::mfma(a, pk[s & 1], dvacc[((s - 8) >> 1) & 1]);
+            else dkacc[((s - 12) >> 1) & 1] = T::mfma(a, sk[s & 1], dkacc[((s - 12) >> 1) & 1]);
+          }
+          // operand four slots ahead (wraps into the next block's row fragments; none past the last block)
+          {
+            const int ns = (s + 4) & 15, nb = b + ((s + 4) >> 4);
+            const bool exists = ns < 8 ? (nb < C::QB) : (nb >= 1 && nb <= C::QB);
+            if (exists) fr[s & 3] = frag(nb, ns);
+          }
+          // VALU of block b-1: exp under slots 0..7, dS = P * (dP - delta) under 8..11;
+          // of block b: exponent arguments under slots 12..15 (S is complete after slot 3)
+          if (prev && s < 8) {
+#pragma unroll
+            for (int e = 2 * s; e < 2 * s + 2; ++e) xP[e] = __builtin_amdgcn_exp2f(xP[e]);
+            if (s == 3) pk[0] = pack8<T, 0>(xP);
+            if (s == 7) pk[1] = pack8<T, 1>(xP);
+          }
+          if (prev && s >= 8 && s < 12) {
+#pragma unroll
+            for (int e = 4 * (s - 8); e < 4 * (s - 8) + 4; ++e) dP_[e] = xP[e] * dP_[e];
+            if (s == 9) sk[0] = pack8<T, 0>(dP_);
+            if (s == 11) sk[1] = pack8<T, 1>(dP_);
+          }
+          if (cur && s >= 12) {
+#pragma unroll
+            for (int e = 4 * (s - 12); e < 4 * (s - 12) + 4; ++e) sacc[e] = __builtin_fmaf(sacc[e], c2, nl[e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cur) {
+          xP = sacc;
+          dP_ = pacc;
+        }
+      }
+    };
+
     auto step_full = [&](int t, auto buf_tag) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_tag)::value;
       const bool more = t + 1 < ntiles;
       if (more) fetch_tile(t + 1, BUF ^ 1);
       FA_STAMP(0);  // DMA issue
+#ifdef FA_DKV_NO_PIPE
 #pragma unroll
       for (int b = 0; b < C::QB; ++b) q_block(BUF, b, 0, std::false_type{});
+#else
+      tile_pipelined(buf_tag);
+#endif
       commit_tile(t + 1, BUF ^ 1, more);
       FA_STAMP(4);  // vmcnt(0) + row constants + barrier
     };
