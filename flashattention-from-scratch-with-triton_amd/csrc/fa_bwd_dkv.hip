@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
-  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  // Row constants of a query tile: wave 0 loads its LSE rows, wave 1 its delta rows, through ONE wave-uniform
+  // descriptor and an unconditional load (a divergent `if` around the load makes hipcc wait vmcnt(0) at the merge,
+  // which also waits for the tile DMA issued just before: the double buffer then hides nothing).
+  const __amdgpu_buffer_rsrc_t rrc =
+      make_rsrc((wave == 0 ? p.lse : p.delta) + (size_t)bh * p.Sq, wave < 2 ? (unsigned)p.Sq * 4 : 0u);
 
   // ---- resident B operands: K^T and V^T of this wave's 32 keys ----
   vec8 kf[C::KS], vf[C::KS];
@@ -125,23 +128,16 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
       dma16(rdo, lds_addr_of(smem + 2 * C::TILE_BYTES + dst), dma_src[i], soff);
     }
-    if (tid < 64) {
-      cst = buf_load_f32(rl, (t * C::BQ + tid) * 4);
-    } else if (tid < 128) {
-      cst = buf_load_f32(rd, (t * C::BQ + tid - 64) * 4);
-    }
+    cst = buf_load_f32(rrc, (t * C::BQ + lane) * 4);
   };
   // tile t (fetched during the previous step) has landed: publish its pre-scaled row constants, then meet
   auto stage_write = [&](int t) __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     FA_LDS float* rc = (FA_LDS float*)(smem + C::ROWC_OFF + (t & 1) * C::ROWC_BYTES);
-    if (tid < 64) {
-      // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
-      rc[tid] = (t * C::BQ + tid < p.Sq) ? -cst * kLog2e : -INFINITY;
-    } else if (tid < 128) {
-      rc[tid] = -cst;  // rc[64 + row] = -delta
-    }
+    // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
+    const float lse_c = (t * C::BQ + lane < p.Sq) ? -cst * kLog2e : -INFINITY;
+    if (wave < 2) rc[tid] = wave == 0 ? lse_c : -cst;  // rc[row] = -LSE*log2e, rc[64 + row] = -delta
   };
 
   auto tile = [&](int t, auto masked_tag) __attribute__((always_inline)) {

@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   using C = Dkv2Cfg;
   using vec8 = typename T::vec8;
   constexpr int D = C::D;
+#ifdef FA_STAMPS
+  unsigned long long clk0_, rt0_;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
@@ -78,8 +82,20 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
-  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  // Row constants of a query tile: the first BQ/64 waves load its LSE rows, the next BQ/64 waves its delta rows,
+  // through ONE wave-uniform descriptor and an unconditional load.  (A divergent `if` around the load makes
+  // hipcc merge the loaded value with a copy, and the s_waitcnt vmcnt(0) it puts before that copy also waits for
+  // the tile DMA issued just above it: the double buffer then hides nothing.)
+  const bool rc_lse = wave < C::BQ / 64, rc_any = wave < 2 * C::BQ / 64;
+  const __amdgpu_buffer_rsrc_t rrc =
+      make_rsrc((rc_lse ? p.lse : p.delta) + (size_t)bh * p.Sq, rc_any ? (unsigned)p.Sq * 4 : 0u);
+  // row of the tile this thread serves; recomputed where it is used (volatile asm, one VALU op): as a loop
+  // invariant hipcc spills it, and a scratch reload is a vmcnt wait just like the one this design avoids
+  auto rc_row_now = [&]() __attribute__((always_inline)) -> int {
+    int x;
+    asm volatile("v_and_b32 %0, %1, %2" : "=v"(x) : "n"(C::BQ - 1), "v"(tid));
+    return x;
+  };
 
   // loop-invariant per-lane addresses
   int dma_src[C::DMA_PER_MAT];
@@ -132,20 +148,21 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
         dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
         dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i], soff);
       }
-      if (tid < C::BQ) rc = buf_load_f32(rl, (t * C::BQ + tid) * 4);                  // waves 0 .. BQ/64-1: LSE rows
-      else if (tid < 2 * C::BQ) rc = buf_load_f32(rd, (t * C::BQ + tid - C::BQ) * 4);  // next BQ/64 waves: delta rows
+      rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4);
     };
     // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet
     auto commit_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      FA_STAMP(6);
       if (fetched) {
         FA_LDS float* rcp = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
         // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
-        if (tid < C::BQ) rcp[tid] = (t * C::BQ + tid < p.Sq) ? -rc * kLog2e : -INFINITY;
-        else if (tid < 2 * C::BQ) rcp[tid] = -rc;  // rcp[BQ + row] = -delta
+        const float lse_c = (t * C::BQ + rc_row_now() < p.Sq) ? -rc * kLog2e : -INFINITY;
+        if (rc_any) rcp[tid] = rc_lse ? lse_c : -rc;  // rcp[row] = -LSE*log2e, rcp[BQ + row] = -delta
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the ds_write above
+      FA_STAMP(7);
 #ifndef FA_ABLATE_BARRIER
       __builtin_amdgcn_s_barrier();
 #endif
@@ -328,6 +345,12 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
             for (int e = 4 * (s - 12); e < 4 * (s - 12) + 4; ++e) sacc[e] = __builtin_fmaf(sacc[e], c2, nl[e]);
           }
           __builtin_amdgcn_sched_barrier(0);
+#ifdef FA_STAMPS
+          if (s == 3) FA_STAMP(1);
+          if (s == 7) FA_STAMP(2);
+          if (s == 11) FA_STAMP(3);
+          if (s == 15) { FA_STAMP(5); if (cur) ++nblk_; }
+#endif
         }
         if (cur) {
           xP = sacc;
@@ -365,9 +388,12 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
 
-    commit_tile(t_start, t_start & 1, t_start < ntiles);  // first tile landed (and K/V fragments)
 #ifdef FA_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
+    commit_tile(t_start, t_start & 1, t_start < ntiles);  // first tile landed (and K/V fragments)
+#ifdef FA_STAMPS
+    seg[4] = seg[6] = seg[7] = 0;
 #endif
 
     int t = t_start;
@@ -390,8 +416,12 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {
     unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-    for (int i = 0; i < 6; ++i) d[i] = seg[i];
+    for (int i = 0; i < 8; ++i) d[i] = seg[i];
     d[8] = nblk_;
+    unsigned long long clk1_, rt1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_)::"memory");
+    d[9] = clk1_ - clk0_;
+    d[10] = rt1_ - rt0_;
   }
 #endif
 }
