@@ -77,12 +77,15 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   const __amdgpu_buffer_rsrc_t rrc =
       make_rsrc((wave == 0 ? p.lse : p.delta) + (size_t)bh * p.Sq, wave < 2 ? (unsigned)p.Sq * 4 : 0u);
 
+  const float c2 = p.scale * kLog2e;
+  constexpr bool FOLD = T::kFoldScale;  // fa_common.h: the score chain starts from -LSE*log2e and K carries c2
   // ---- resident B operands: K^T and V^T of this wave's 32 keys ----
   vec8 kf[C::KS], vf[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
     const int off = (kw0 + r) * C::ROWB + (2 * ks + h) * 16;
     kf[ks] = as_vec8<T>(buf_load16(rk, off));
+    if constexpr (FOLD) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
     vf[ks] = as_vec8<T>(buf_load16(rv, off));
   }
 
@@ -108,7 +111,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
 #pragma unroll
     for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
 
-  const float c2 = p.scale * kLog2e;
   f32x16 dkacc[C::DB], dvacc[C::DB];
 #pragma unroll
   for (int db = 0; db < C::DB; ++db)
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       const FA_LDS char* qbp = qt + b * 32 * C::ROWB;
       const FA_LDS char* dbp = dt + b * 32 * C::ROWB;
       // per-register row constants: reg i <-> row (i&3) + 8(i>>2) + 4h
+      // both MFMA chains START from them: with K pre-scaled the first delivers s*c2 - LSE*log2e, the second dP - delta
       f32x16 nl, pacc, sacc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -164,11 +167,10 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           nl[4 * g + j] = a[j];
+          sacc[4 * g + j] = FOLD ? a[j] : 0.f;
           pacc[4 * g + j] = d[j];
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float x = __builtin_fmaf(sacc[i], c2, nl[i]);
+        float x = FOLD ? sacc[i] : __builtin_fmaf(sacc[i], c2, nl[i]);
         if constexpr (MASKED) {
           const int qrow = qb0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           x = (kw0 + r > qrow) ? -INFINITY : x;

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 #pragma unroll
     for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
   const float c2 = p.scale * kLog2e;
+  constexpr bool FOLD = T::kFoldScale;  // fa_common.h: the score chain starts from -LSE*log2e and K carries c2
   const int ntiles = (p.Sq + C::BQ - 1) / C::BQ;
 
   // A ragged last query tile leaves its tail rows to an out-of-range DMA; make sure those LDS bytes
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     for (int ks = 0; ks < C::KS; ++ks) {
       const int off = (kw0 + r) * C::ROWB + (2 * ks + h) * 16;
       kf[ks] = as_vec8<T>(buf_load16(rk, off));
+      if constexpr (FOLD) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
       vf[ks] = as_vec8<T>(buf_load16(rv, off));
     }
     f32x16 dkacc[C::DB], dvacc[C::DB];
@@ -201,11 +203,10 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           nl[4 * g + j] = a[j];
+          sacc[4 * g + j] = FOLD ? a[j] : 0.f;  // FOLD: the chains start from -LSE*log2e and -delta
           pacc[4 * g + j] = d[j];
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float x = __builtin_fmaf(sacc[i], c2, nl[i]);
+        float x = FOLD ? sacc[i] : __builtin_fmaf(sacc[i], c2, nl[i]);
         if constexpr (MASKED) {
           const int qrow = qb0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           x = (kw0 + r > qrow) ? -INFINITY : x;
@@ -285,31 +286,43 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
         const FA_LDS char* base = (n < 4 ? dt : qt) + (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
         return lds_read_tr_frag<T>(base + tr_off[0][db], base + tr_off[1][db]);
       };
-      f32x16 xP, dP_;               // previous block: exponent argument s*c2 - LSE*log2e, and dP - delta
-      vec8 pk[2], sk[2];            // previous block: packed P and dS fragments (k-steps 0, 1)
+      // row constants of block b, group g (registers 4g..4g+3 <-> rows 8g + 4h + 0..3): the accumulators START
+      // from them, so the MFMA chains deliver  s*c2 - LSE*log2e  (K is pre-scaled by c2) and  dP - delta
+      auto rowc = [&](int b, int g, f32x16& s0, f32x16& p0) __attribute__((always_inline)) {
+        const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * g + 4 * h) * 4);
+        const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * g + 4 * h) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0[4 * g + j] = a[j];
+          p0[4 * g + j] = d[j];
+        }
+      };
+      f32x16 xP, dP_;               // previous block: exponent argument -> P, and dP - delta -> dS
+      u32x4 pk[2], sk[2];           // previous block: packed P and dS fragments (k-steps 0, 1), built dword by dword
       vec8 fr[4];                   // operand ring, four slots deep
+      f32x16 sacc, pacc;            // this block's accumulators
+      f32x16 nl;                    // exact mode (!FOLD): -LSE*log2e of this block, added by an fma under slots 12..15
 #pragma unroll
       for (int s = 0; s < 4; ++s) fr[s] = frag(0, s);
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rowc(0, g, sacc, pacc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b <= C::QB; ++b) {
         const bool cur = b < C::QB;   // block b exists: slots 0..7
         const bool prev = b > 0;      // block b-1 exists: slots 8..15 and its VALU work
-        f32x16 nl, pacc, sacc;
-        if (cur) {
+        f32x16 sn, pn;                // FOLD: next block's starting accumulators (read under slots 12..15)
+        if constexpr (!FOLD) {
+          if (cur) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * g + 4 * h) * 4);
-            const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * g + 4 * h) * 4);
+            for (int g = 0; g < 4; ++g) rowc(b, g, nl, pacc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              nl[4 * g + j] = a[j];
-              pacc[4 * g + j] = d[j];
-            }
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
           }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const bool active = s < 8 ? cur : prev;
@@ -317,8 +330,8 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
             const vec8 a = fr[s & 3];
             if (s < 4) sacc = T::mfma(a, kf[s], sacc);
             else if (s < 8) pacc = T::mfma(a, vf[s - 4], pacc);
-            else if (s < 12) dvacc[((s - 8) >> 1) & 1] = T::mfma(a, pk[s & 1], dvacc[((s - 8) >> 1) & 1]);
-            else dkacc[((s - 12) >> 1) & 1] = T::mfma(a, sk[s & 1], dkacc[((s - 12) >> 1) & 1]);
+            else if (s < 12) dvacc[((s - 8) >> 1) & 1] = T::mfma(a, as_vec8<T>(pk[s & 1]), dvacc[((s - 8) >> 1) & 1]);
+            else dkacc[((s - 12) >> 1) & 1] = T::mfma(a, as_vec8<T>(sk[s & 1]), dkacc[((s - 12) >> 1) & 1]);
           }
           // operand four slots ahead (wraps into the next block's row fragments; none past the last block)
           {
@@ -326,23 +339,31 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
             const bool exists = ns < 8 ? (nb < C::QB) : (nb >= 1 && nb <= C::QB);
             if (exists) fr[s & 3] = frag(nb, ns);
           }
-          // VALU of block b-1: exp under slots 0..7, dS = P * (dP - delta) under 8..11;
-          // of block b: exponent arguments under slots 12..15 (S is complete after slot 3)
+          if constexpr (FOLD) {
+            if (s >= 12 && b + 1 < C::QB) rowc(b + 1, s - 12, sn, pn);
+          } else {
+            if (cur && s >= 12) {
+#pragma unroll
+              for (int e = 4 * (s - 12); e < 4 * (s - 12) + 4; ++e) sacc[e] = __builtin_fmaf(sacc[e], c2, nl[e]);
+            }
+          }
+          // VALU of block b-1, a few ops per slot: exp under slots 0..7 with the pack of the pair done one slot
+          // later, dS = P * (dP - delta) under 8..11 with its packs under 9..12
           if (prev && s < 8) {
 #pragma unroll
             for (int e = 2 * s; e < 2 * s + 2; ++e) xP[e] = __builtin_amdgcn_exp2f(xP[e]);
-            if (s == 3) pk[0] = pack8<T, 0>(xP);
-            if (s == 7) pk[1] = pack8<T, 1>(xP);
+          }
+          if (prev && s >= 1 && s <= 8) {
+            const int e = 2 * (s - 1);
+            pk[e >> 3][(e & 7) >> 1] = pack2<T>(xP[e], xP[e + 1]);
           }
           if (prev && s >= 8 && s < 12) {
 #pragma unroll
             for (int e = 4 * (s - 8); e < 4 * (s - 8) + 4; ++e) dP_[e] = xP[e] * dP_[e];
-            if (s == 9) sk[0] = pack8<T, 0>(dP_);
-            if (s == 11) sk[1] = pack8<T, 1>(dP_);
           }
-          if (cur && s >= 12) {
+          if (prev && s >= 9 && s <= 12) {
 #pragma unroll
-            for (int e = 4 * (s - 12); e < 4 * (s - 12) + 4; ++e) sacc[e] = __builtin_fmaf(sacc[e], c2, nl[e]);
+            for (int e = 4 * (s - 9); e < 4 * (s - 9) + 4; e += 2) sk[e >> 3][(e & 7) >> 1] = pack2<T>(dP_[e], dP_[e + 1]);
           }
           __builtin_amdgcn_sched_barrier(0);
 #ifdef FA_STAMPS
@@ -355,6 +376,12 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
         if (cur) {
           xP = sacc;
           dP_ = pacc;
+        }
+        if constexpr (FOLD) {
+          if (b + 1 < C::QB) {
+            sacc = sn;
+            pacc = pn;
+          }
         }
       }
     };

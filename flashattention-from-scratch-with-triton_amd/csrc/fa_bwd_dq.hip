@@ -85,9 +85,21 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
   const float delta = half_sum(dsum);
   const float nl = -buf_load_f32(rl, (qw0 + r) * 4) * kLog2e;
   if (h == 0) buf_store_f32(rd, (qw0 + r) * 4, delta);
-  f32x16 ndelta;
+  // Both MFMA chains START from a block holding this lane's (= query row's) constant: with Q pre-scaled by
+  // softmax_scale*log2(e) the first delivers the exponent argument s*c2 - LSE*log2e, the second dP - delta,
+  // and no per-element fma / subtract is left in the hot loop.
+  f32x16 ndelta, nlse;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) ndelta[i] = -delta;
+  for (int i = 0; i < 16; ++i) {
+    ndelta[i] = -delta;
+    nlse[i] = T::kFoldScale ? nl : 0.f;
+  }
+  const float c2 = p.scale * kLog2e;
+  constexpr bool FOLD = T::kFoldScale;  // fa_common.h
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) qf[ks] = scale_frag<T>(qf[ks], c2);
+  }
 
   const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
   const int ntiles = (kv_end + C::BN - 1) / C::BN;
@@ -110,7 +122,6 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
 #pragma unroll
     for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
 
-  const float c2 = p.scale * kLog2e;
   f32x16 dqacc[C::DB];
 #pragma unroll
   for (int db = 0; db < C::DB; ++db)
@@ -147,9 +158,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
       }
       const FA_LDS char* kbp = kt + b * 32 * C::ROWB;
       const FA_LDS char* vbp = vt + b * 32 * C::ROWB;
-      f32x16 sacc, pacc = ndelta;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+      f32x16 sacc = nlse, pacc = ndelta;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(kbp + row_off[ks]));
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float x = __builtin_fmaf(sacc[i], c2, nl);
+        float x = FOLD ? sacc[i] : __builtin_fmaf(sacc[i], c2, nl);
         if constexpr (MASKED) {
           const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
           const bool dead = (CAUSAL && key > qw0 + r) || key >= p.Sk;
