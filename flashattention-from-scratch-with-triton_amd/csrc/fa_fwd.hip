@@ -114,8 +114,19 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     for (int db = 0; db < C::DB; ++db) v_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
 
   const float c2 = p.scale * kLog2e;  // exp(x*scale) = exp2(x*c2)
-  const float defer_raw = kDeferLog2 / c2;  // rescale threshold in raw-score units
-  float m = -INFINITY;                // running row max of the RAW scores (before scale)
+  // FOLD (bf16, fa_common.h): Q carries c2, the MFMA delivers scores in log2 units (cs = 1) and a lazy tile's
+  // score chain starts from a block holding -m, so its exponent argument needs no VALU op at all.
+  constexpr bool FOLD = T::kFoldScale;
+  const float cs = FOLD ? 1.0f : c2;  // accumulator units -> log2 units
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) qf[ks] = scale_frag<T>(qf[ks], c2);
+  }
+  const float defer_raw = kDeferLog2 / cs;  // rescale threshold in accumulator units
+  float m = -INFINITY;                // running row max in accumulator units (raw scores, or log2 units if FOLD)
+  f32x16 negm;                        // FOLD: -m in every register (this lane's query row)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = INFINITY;
   float l = 0.f;                      // this lane's partial row sum (its 16 of every 32 keys)
   f32x16 oacc[C::DB];
 #pragma unroll
@@ -198,21 +209,25 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     // rounding in 16 bit) and the O-wide multiply is rare.  m = -inf (first tile) always fires.
     if (__builtin_amdgcn_ballot_w64(tm > m + defer_raw) != 0) {
       const float mn = __builtin_fmaxf(m, tm);
-      const float corr = __builtin_amdgcn_exp2f((m - mn) * c2);  // m = -inf -> 0
+      const float corr = __builtin_amdgcn_exp2f((m - mn) * cs);  // m = -inf -> 0
       l *= corr;
 #pragma unroll
       for (int db = 0; db < C::DB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[db][i] *= corr;
       m = mn;
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = -mn;
+      }
     }
-    const float mc = m * c2;
+    const float mc = m * cs;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][i], c2, -mc));
+        const float pe = __builtin_amdgcn_exp2f(FOLD ? sacc[b][i] - mc : __builtin_fmaf(sacc[b][i], c2, -mc));
         sacc[b][i] = pe;
         ls[i & 3] += pe;
       }
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[b][i] = 0.f;
+      for (int i = 0; i < 16; ++i) sacc[b][i] = FOLD ? negm[i] : 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][i], c2, -mc));
+        const float pe = __builtin_amdgcn_exp2f(FOLD ? sacc[b][i] : __builtin_fmaf(sacc[b][i], c2, -mc));
         sacc[b][i] = pe;
         ls[i & 3] += pe;
       }
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   const float inv = 1.0f / lt;
   // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
   store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * C::ROWB, lane);
-  if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * p.scale + __builtin_logf(lt));
+  if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
   }  // pass
 }
 
