@@ -43,9 +43,12 @@ struct BwdParams {
 // forward / dQ; family 2 wins on large non-causal grids and for dK/dV at S_q >= 2048.
 // fa_debug_force_impl() (not in the public header) overrides the rule for tests and A/B runs; 0 = rule.
 extern int g_force_fwd, g_force_dq, g_force_dkv;
-inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal) {
+// `fold_fwd`: the bf16 forward, whose family-1 lazy tiles need no VALU op before exp2 (fa_common.h kFoldScale):
+// family 1 then wins on every grid measured (non-causal B4 H32 S4096: 1040 vs 1007 TFLOPS; S8192: 1052 vs 1018).
+inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal, bool fold_fwd = false) {
   if (D != 64) return 1;
   if (forced) return forced;
+  if (fold_fwd) return 1;
   const long tiles256 = (Sq + 255) / 256;
   const long wgs2 = (long)B * H * (causal ? (tiles256 + 1) / 2 : tiles256);
   return (!causal && wgs2 >= 512) ? 2 : 1;
