@@ -35,8 +35,9 @@ struct DqCfg {
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;
 };
 
-template <int D, typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
+// OCC = workgroups per CU the register allocation is held to (2: 256 VGPRs, 3: 168).
+template <int D, typename T, bool CAUSAL, int OCC>
+__global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   using C = DqCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -139,7 +140,11 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
   };
   auto tile_sync = [&]() __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    // vmcnt(0): the tile fetched during this step has landed.  lgkmcnt(0): every LDS read this wave has ISSUED on the
+    // current tile has also RETURNED -- hipcc is free to sink the wait + MFMA of the last fragment below the barrier,
+    // and a read still queued in the LDS pipeline then races the other waves' next DMA / epilogue staging into the
+    // same buffer (seen as a rare wrong 32x32 block of one wave once three workgroups shared a CU).
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -213,11 +218,17 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(BwdParams p) {
   }  // pass
 }
 
-template <int D, typename T, bool CAUSAL>
+template <int D, typename T, bool CAUSAL, int OCC = 2>
 static hipError_t launch(const BwdParams& p, hipStream_t s) {
   using C = DqCfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
-  auto kern = fa_bwd_dq_kernel<D, T, CAUSAL>;
+  // Three workgroups per CU pay off for the bf16 kernel (no fma/sub in its hot loop, fa_common.h kFoldScale) once
+  // the grid fills them: +3 % causal, +7 % non-causal at B4 H32 N4096.  The tighter register budget spills in
+  // the prologue only, which costs small grids more than the occupancy gives (B4 H8 S1024: -16 %); fp16: no gain.
+  if constexpr (OCC == 2 && D == 64 && T::kFoldScale) {
+    if (grid >= 3 * 256) return launch<D, T, CAUSAL, 3>(p, s);
+  }
+  auto kern = fa_bwd_dq_kernel<D, T, CAUSAL, OCC>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -229,7 +240,8 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v2.hip
 
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  if (pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0) == 2) return launch_bwd_dq_v2(p, dtype, causal, s);
+  if (pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
+    return launch_bwd_dq_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))

@@ -25,7 +25,8 @@ struct Dq2Cfg {
   static constexpr int DMA_PER_MAT = TILE_BYTES / (NW * 1024);
 };
 
-#define FA_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
+// vmcnt(n) AND lgkmcnt(0): LDS reads issued on the current tile must have returned before the barrier (see fa_fwd.hip)
+#define FA_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0070 | (n))
 
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {

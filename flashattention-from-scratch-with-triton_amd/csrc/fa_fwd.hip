@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   // the tile fetched during this step has landed (vmcnt(0)); every wave is done with the current one
   auto tile_sync = [&]() __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // vmcnt(0): the tile fetched during this step has landed.  lgkmcnt(0): every LDS read this wave has ISSUED on the
+    // current tile has also RETURNED -- hipcc is free to sink the wait + MFMA of the last fragment below the barrier,
+    // and a read still queued in the LDS pipeline then races the other waves' next DMA / epilogue staging into the
+    // same buffer (seen as a rare wrong 32x32 block of one wave once three workgroups shared a CU).
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };

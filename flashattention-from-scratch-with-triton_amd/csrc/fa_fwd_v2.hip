@@ -49,7 +49,8 @@ struct Fwd2Cfg {
 #endif
 
 // s_waitcnt vmcnt(n) only (lgkmcnt / expcnt untouched), n < 16
-#define FA_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
+// vmcnt(n) AND lgkmcnt(0): LDS reads issued on the current tile must have returned before the barrier (see fa_fwd.hip)
+#define FA_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0070 | (n))
 
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {

@@ -40,15 +40,16 @@ struct BwdParams {
 //   1 = 128-row (128-key) workgroups, 32 rows per wave, up to 3 waves per SIMD  (also the only D = 128 path)
 //   2 = 256-row workgroups, 64 rows per wave sharing every K/V fragment (forward, dQ); 128-row Q/dO tiles (dK/dV)
 // Measured on MI355X (profiles/r01_schedule_selection.txt): family 1 wins on small grids and on causal
-// forward / dQ; family 2 wins on large non-causal grids and for dK/dV at S_q >= 2048.
+// forward / dQ; family 2 wins on large non-causal grids (fp16 forward, dQ) and for dK/dV from S_q = 256 up.
 // fa_debug_force_impl() (not in the public header) overrides the rule for tests and A/B runs; 0 = rule.
 extern int g_force_fwd, g_force_dq, g_force_dkv;
-// `fold_fwd`: the bf16 forward, whose family-1 lazy tiles need no VALU op before exp2 (fa_common.h kFoldScale):
-// family 1 then wins on every grid measured (non-causal B4 H32 S4096: 1040 vs 1007 TFLOPS; S8192: 1052 vs 1018).
-inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal, bool fold_fwd = false) {
+// `fold`: the bf16 kernels, whose family-1 hot loops start the score chain from the row constant (fa_common.h
+// kFoldScale): family 1 then wins on every grid measured (non-causal B4 H32 S4096: forward 1040 vs 1007 TFLOPS,
+// dQ at three workgroups per CU 1161 vs 1135; S8192: forward 1052 vs 1018).
+inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal, bool fold = false) {
   if (D != 64) return 1;
   if (forced) return forced;
-  if (fold_fwd) return 1;
+  if (fold) return 1;
   const long tiles256 = (Sq + 255) / 256;
   const long wgs2 = (long)B * H * (causal ? (tiles256 + 1) / 2 : tiles256);
   return (!causal && wgs2 >= 512) ? 2 : 1;
@@ -56,7 +57,7 @@ inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal
 inline int pick_dkv_impl(int forced, int D, int Sq) {
   if (D != 64) return 1;
   if (forced) return forced;
-  return Sq >= 2048 ? 2 : 1;
+  return Sq >= 256 ? 2 : 1;  // profiles/r01_schedule_selection.txt: the pipelined family 2 wins from S = 256 up
 }
 
 // Causal tile pairing equalises the work per workgroup but halves the number of workgroups: worth it as

@@ -1,0 +1,28 @@
+import os, sys, torch, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flashattention-from-scratch-with-triton_amd"))
+import My_FlashAttention_optimized as M
+import _scaling as sc
+import _mi355fa as fa
+Q, K, V, dO = sc.make_shard(0, 4, 32, 4096, 4096, 64, torch.bfloat16, torch.device("cuda"))
+O, LSE = M.flash_attention_forward(Q, K, V, True)
+def dq_only():
+    dQ = torch.empty_like(Q); delta = torch.empty_like(LSE)
+    st = torch.cuda.current_stream().cuda_stream
+    fa.check(fa.lib.fa_bwd_dq(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), LSE.data_ptr(),
+                              dQ.data_ptr(), delta.data_ptr(), 4, 32, 4096, 4096, 64, 1, 1, 0.125, st), "fa_bwd_dq")
+    torch.cuda.synchronize()
+    return dQ, delta
+a, da = dq_only()
+for it in range(12):
+    b, db = dq_only()
+    d = (a.float() - b.float()).abs()
+    idx = (d > 0).nonzero()
+    print("run", it, "dQ differing elements:", len(idx), "max", d.max().item(), "delta equal:", torch.equal(da, db))
+    if len(idx):
+        rows = idx[:, 2]
+        print("  bh:", sorted(set((idx[:, 0] * 32 + idx[:, 1]).tolist()))[:12], " rows min/max", rows.min().item(), rows.max().item())
+        print("  row%128 hist(16 bins):", torch.bincount((rows % 128) // 8, minlength=16).tolist())
+        print("  row//128 (q tile) set:", sorted(set((rows // 128).tolist()))[:20])
+        print("  cols hist(8 bins):", torch.bincount(idx[:, 3] // 8, minlength=8).tolist())
+        print("  sample:", idx[:5].tolist(), a[tuple(idx[0])].item(), b[tuple(idx[0])].item())
