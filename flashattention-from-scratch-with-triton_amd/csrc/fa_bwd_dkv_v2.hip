@@ -1,4 +1,5 @@
-// FlashAttention backward dK / dV, head dim 64, second-generation schedule for gfx950.
+// FlashAttention backward dK / dV, second-generation schedule for gfx950 (head dim 64: two workgroups per CU;
+// head dim 128: one, accumulators partly in AGPRs).
 //
 // Same maths and rounding points as fa_bwd_dkv.hip (reference kernel
 // code/_flash_attention_kernel_optimized.py:292-386; runs after the dQ kernel and reads its delta).
@@ -24,8 +25,9 @@ namespace fa {
 #define FA_DKV_BQ 128  // query rows per LDS tile
 #endif
 
+template <int D_>
 struct Dkv2Cfg {
-  static constexpr int D = 64;
+  static constexpr int D = D_;
   static constexpr int BK = 128, BQ = FA_DKV_BQ, NT = 256, NW = 4;
   static constexpr int QB = BQ / 32;                       // 32-row query blocks per tile
   static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
@@ -35,6 +37,7 @@ struct Dkv2Cfg {
   static constexpr int ROWC_BYTES = 2 * BQ * 4;
   static constexpr int LDS_BYTES = 4 * TILE_BYTES + 2 * ROWC_BYTES;  // 66 KiB at BQ = 128
   static constexpr int DMA_PER_MAT = TILE_BYTES / (NW * 1024);
+  static constexpr int RPI = 1024 / ROWB;                  // tile rows per 1-KiB DMA instruction
 };
 
 #ifdef FA_STAMPS
@@ -51,11 +54,10 @@ struct Dkv2Cfg {
 #define FA_STAMP(slot) do {} while (0)
 #endif
 
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
-  using C = Dkv2Cfg;
+template <int D, typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdParams p) {
+  using C = Dkv2Cfg<D>;
   using vec8 = typename T::vec8;
-  constexpr int D = C::D;
 #ifdef FA_STAMPS
   unsigned long long clk0_, rt0_;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
   int dma_src[C::DMA_PER_MAT];
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
-    const int row = (C::BQ / C::NW) * wave + 8 * i + (lane >> 3);
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane & 7) * 16;
+    const int row = (C::BQ / C::NW) * wave + C::RPI * i + lane / C::CPR;
+    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
   int row_off[C::KS];
 #pragma unroll
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       const int soff = t * C::TILE_BYTES;
 #pragma unroll
       for (int i = 0; i < C::DMA_PER_MAT; ++i) {
-        const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + 8 * i) * C::ROWB;
+        const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * i) * C::ROWB;
         dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
         dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i], soff);
       }
@@ -272,19 +274,24 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
     // are ~140 cycles ahead and the VALU work hides in the issue cycles the MFMAs leave free.
     auto tile_pipelined = [&](auto buf_tag) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_tag)::value;
+      constexpr int KS = C::KS, DB = C::DB;
+      // slot map of one block: [0, P0) S, [P0, V0) dP (block b); [V0, K0) dV^T, [K0, NS) dK^T (block b-1)
+      constexpr int P0 = KS, V0 = 2 * KS, K0 = 2 * KS + 2 * DB, NS = 2 * KS + 4 * DB;
+      constexpr int EPS = 16 / V0;          // exps per slot under S / dP            (D=64: 2, D=128: 1)
+      constexpr int MPS = 16 / (2 * DB);    // dS multiplies (or fmas) per dV (dK) slot (D=64: 4, D=128: 2)
       const FA_LDS char* qt = smem + BUF * C::TILE_BYTES;
       const FA_LDS char* dt = smem + C::DO_BASE + BUF * C::TILE_BYTES;
       const FA_LDS char* rcp = smem + C::ROWC_OFF + BUF * C::ROWC_BYTES;
-      // operand fragment of slot s of block b (block index QB = the drain pass: only slots 8..15 exist)
+      // operand fragment of slot s of block b (block index QB = the drain pass: only the slots from V0 on exist)
       auto frag = [&](int b, int s) __attribute__((always_inline)) -> vec8 {
-        if (s < 8) {  // row fragments of block b: Q rows (k-steps 0..3), then dO rows
-          const FA_LDS char* base = (s < 4 ? qt : dt) + b * 32 * C::ROWB;
-          return as_vec8<T>(lds_read16(base + row_off[s & 3]));
+        if (s < V0) {  // row fragments of block b: Q rows (k-steps 0..KS-1), then dO rows
+          const FA_LDS char* base = (s < P0 ? qt : dt) + b * 32 * C::ROWB;
+          return as_vec8<T>(lds_read16(base + row_off[s < P0 ? s : s - P0]));
         }
-        // transposed fragments of block b-1: dO^T (d block 0: k-steps 0,1; d block 1: 0,1), then Q^T
-        const int n = s - 8, db = (n >> 1) & 1;
-        const FA_LDS char* base = (n < 4 ? dt : qt) + (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
-        return lds_read_tr_frag<T>(base + tr_off[0][db], base + tr_off[1][db]);
+        // transposed fragments of block b-1: dO^T (d block n>>1, k-step n&1), then Q^T
+        const int n = s < K0 ? s - V0 : s - K0;
+        const FA_LDS char* base = (s < K0 ? dt : qt) + (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
+        return lds_read_tr_frag<T>(base + tr_off[0][n >> 1], base + tr_off[1][n >> 1]);
       };
       // row constants of block b, group g (registers 4g..4g+3 <-> rows 8g + 4h + 0..3): the accumulators START
       // from them, so the MFMA chains deliver  s*c2 - LSE*log2e  (K is pre-scaled by c2) and  dP - delta
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       u32x4 pk[2], sk[2];           // previous block: packed P and dS fragments (k-steps 0, 1), built dword by dword
       vec8 fr[4];                   // operand ring, four slots deep
       f32x16 sacc, pacc;            // this block's accumulators
-      f32x16 nl;                    // exact mode (!FOLD): -LSE*log2e of this block, added by an fma under slots 12..15
+      f32x16 nl;                    // exact mode (!FOLD): -LSE*log2e of this block, added by an fma under the dK slots
 #pragma unroll
       for (int s = 0; s < 4; ++s) fr[s] = frag(0, s);
       if constexpr (FOLD) {
@@ -311,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b <= C::QB; ++b) {
-        const bool cur = b < C::QB;   // block b exists: slots 0..7
-        const bool prev = b > 0;      // block b-1 exists: slots 8..15 and its VALU work
-        f32x16 sn, pn;                // FOLD: next block's starting accumulators (read under slots 12..15)
+        const bool cur = b < C::QB;   // block b exists: S / dP slots
+        const bool prev = b > 0;      // block b-1 exists: dV / dK slots and its VALU work
+        f32x16 sn, pn;                // FOLD: next block's starting accumulators (read under the dK slots)
         if constexpr (!FOLD) {
           if (cur) {
 #pragma unroll
@@ -324,53 +331,57 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const bool active = s < 8 ? cur : prev;
+        for (int s = 0; s < NS; ++s) {
+          const bool active = s < V0 ? cur : prev;
           if (active) {
             const vec8 a = fr[s & 3];
-            if (s < 4) sacc = T::mfma(a, kf[s], sacc);
-            else if (s < 8) pacc = T::mfma(a, vf[s - 4], pacc);
-            else if (s < 12) dvacc[((s - 8) >> 1) & 1] = T::mfma(a, as_vec8<T>(pk[s & 1]), dvacc[((s - 8) >> 1) & 1]);
-            else dkacc[((s - 12) >> 1) & 1] = T::mfma(a, as_vec8<T>(sk[s & 1]), dkacc[((s - 12) >> 1) & 1]);
+            if (s < P0) sacc = T::mfma(a, kf[s], sacc);
+            else if (s < V0) pacc = T::mfma(a, vf[s - P0], pacc);
+            else if (s < K0) dvacc[(s - V0) >> 1] = T::mfma(a, as_vec8<T>(pk[(s - V0) & 1]), dvacc[(s - V0) >> 1]);
+            else dkacc[(s - K0) >> 1] = T::mfma(a, as_vec8<T>(sk[(s - K0) & 1]), dkacc[(s - K0) >> 1]);
           }
           // operand four slots ahead (wraps into the next block's row fragments; none past the last block)
           {
-            const int ns = (s + 4) & 15, nb = b + ((s + 4) >> 4);
-            const bool exists = ns < 8 ? (nb < C::QB) : (nb >= 1 && nb <= C::QB);
+            const int ns = (s + 4) % NS, nb = b + (s + 4) / NS;
+            const bool exists = ns < V0 ? (nb < C::QB) : (nb >= 1 && nb <= C::QB);
             if (exists) fr[s & 3] = frag(nb, ns);
           }
-          if constexpr (FOLD) {
-            if (s >= 12 && b + 1 < C::QB) rowc(b + 1, s - 12, sn, pn);
+          if constexpr (FOLD) {  // next block's row constants, one group per 2*DB/4 dK slots
+            if (s >= K0 && (s - K0) % (2 * DB / 4) == 0 && b + 1 < C::QB) rowc(b + 1, (s - K0) / (2 * DB / 4), sn, pn);
           } else {
-            if (cur && s >= 12) {
+            if (cur && s >= K0) {
 #pragma unroll
-              for (int e = 4 * (s - 12); e < 4 * (s - 12) + 4; ++e) sacc[e] = __builtin_fmaf(sacc[e], c2, nl[e]);
+              for (int e = MPS * (s - K0); e < MPS * (s - K0) + MPS; ++e) sacc[e] = __builtin_fmaf(sacc[e], c2, nl[e]);
             }
           }
-          // VALU of block b-1, a few ops per slot: exp under slots 0..7 with the pack of the pair done one slot
-          // later, dS = P * (dP - delta) under 8..11 with its packs under 9..12
-          if (prev && s < 8) {
+          // VALU of block b-1, a few ops per slot: exp under the S / dP slots with the pack of each pair one slot
+          // after its second exp; dS = P * (dP - delta) under the dV slots with its packs one slot later
+          if (prev && s < V0) {
 #pragma unroll
-            for (int e = 2 * s; e < 2 * s + 2; ++e) xP[e] = __builtin_amdgcn_exp2f(xP[e]);
+            for (int e = EPS * s; e < EPS * s + EPS; ++e) xP[e] = __builtin_amdgcn_exp2f(xP[e]);
           }
-          if (prev && s >= 1 && s <= 8) {
-            const int e = 2 * (s - 1);
-            pk[e >> 3][(e & 7) >> 1] = pack2<T>(xP[e], xP[e + 1]);
-          }
-          if (prev && s >= 8 && s < 12) {
+          if (prev) {
 #pragma unroll
-            for (int e = 4 * (s - 8); e < 4 * (s - 8) + 4; ++e) dP_[e] = xP[e] * dP_[e];
+            for (int j = 0; j < 8; ++j) {  // pair j = registers 2j, 2j+1
+              if ((2 * j + 1) / EPS + 1 == s) pk[j >> 2][j & 3] = pack2<T>(xP[2 * j], xP[2 * j + 1]);
+            }
           }
-          if (prev && s >= 9 && s <= 12) {
+          if (prev && s >= V0 && s < K0) {
 #pragma unroll
-            for (int e = 4 * (s - 9); e < 4 * (s - 9) + 4; e += 2) sk[e >> 3][(e & 7) >> 1] = pack2<T>(dP_[e], dP_[e + 1]);
+            for (int e = MPS * (s - V0); e < MPS * (s - V0) + MPS; ++e) dP_[e] = xP[e] * dP_[e];
+          }
+          if (prev) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (V0 + (2 * j + 1) / MPS + 1 == s) sk[j >> 2][j & 3] = pack2<T>(dP_[2 * j], dP_[2 * j + 1]);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #ifdef FA_STAMPS
-          if (s == 3) FA_STAMP(1);
-          if (s == 7) FA_STAMP(2);
-          if (s == 11) FA_STAMP(3);
-          if (s == 15) { FA_STAMP(5); if (cur) ++nblk_; }
+          if (s == P0 - 1) FA_STAMP(1);
+          if (s == V0 - 1) FA_STAMP(2);
+          if (s == K0 - 1) FA_STAMP(3);
+          if (s == NS - 1) { FA_STAMP(5); if (cur) ++nblk_; }
 #endif
         }
         if (cur) {
@@ -453,11 +464,11 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv2_kernel(BwdParams p) {
 #endif
 }
 
-template <typename T, bool CAUSAL>
+template <int D, typename T, bool CAUSAL>
 static hipError_t launch2(const BwdParams& p, hipStream_t s) {
-  using C = Dkv2Cfg;
+  using C = Dkv2Cfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
-  auto kern = fa_bwd_dkv2_kernel<T, CAUSAL>;
+  auto kern = fa_bwd_dkv2_kernel<D, T, CAUSAL>;
   static const int pad = getenv("FA_LDS_PAD") ? atoi(getenv("FA_LDS_PAD")) : 0;  // diagnostic: force 1 workgroup per CU
   if (C::LDS_BYTES + pad > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + pad);
@@ -471,11 +482,14 @@ static hipError_t launch2(const BwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_bwd_dkv_v2(BwdParams p, int dtype, int causal, hipStream_t s) {
-  p.n_tiles = (p.Sk + Dkv2Cfg::BK - 1) / Dkv2Cfg::BK;
+hipError_t launch_bwd_dkv_v2(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  p.n_tiles = (p.Sk + 127) / 128;  // Dkv2Cfg::BK
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
-  if (dtype == 1) return causal ? launch2<BF16, true>(p, s) : launch2<BF16, false>(p, s);
-  return causal ? launch2<FP16, true>(p, s) : launch2<FP16, false>(p, s);
+#define FA_GO(DD, TT) (causal ? launch2<DD, TT, true>(p, s) : launch2<DD, TT, false>(p, s))
+  if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
+  if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
+#undef FA_GO
+  return hipErrorInvalidValue;
 }
 
 }  // namespace fa

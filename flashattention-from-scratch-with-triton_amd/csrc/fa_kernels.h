@@ -38,7 +38,8 @@ struct BwdParams {
 // ---- schedule selection (the counterpart of the reference's autotune key (S_q, S_k, D, is_causal),
 // K:18-32): a static rule per kernel instead of a run-time search.  Two schedule families exist for D = 64:
 //   1 = 128-row (128-key) workgroups, 32 rows per wave, up to 3 waves per SIMD  (also the only D = 128 path)
-//   2 = 256-row workgroups, 64 rows per wave sharing every K/V fragment (forward, dQ); 128-row Q/dO tiles (dK/dV)
+//   2 = 256-row workgroups, 64 rows per wave sharing every K/V fragment (forward, dQ: D = 64 only); 128-row Q/dO
+//       tiles and the hand-ordered pipeline (dK/dV: D = 64 and 128)
 // Measured on MI355X (profiles/r01_schedule_selection.txt): family 1 wins on small grids and on causal
 // forward / dQ; family 2 wins on large non-causal grids (fp16 forward, dQ) and for dK/dV from S_q = 256 up.
 // fa_debug_force_impl() (not in the public header) overrides the rule for tests and A/B runs; 0 = rule.
@@ -55,7 +56,7 @@ inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal
   return (!causal && wgs2 >= 512) ? 2 : 1;
 }
 inline int pick_dkv_impl(int forced, int D, int Sq) {
-  if (D != 64) return 1;
+  if (D != 64 && D != 128) return 1;
   if (forced) return forced;
   return Sq >= 256 ? 2 : 1;  // profiles/r01_schedule_selection.txt: the pipelined family 2 wins from S = 256 up
 }
