@@ -26,16 +26,33 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _in_place(*tensors):
+    """The reference makes every input contiguous (M:138-140,156): a 64 MiB copy per tensor at the headline size
+    whenever Q/K/V are transposed views of a fused projection ([B,S,H,D] seen as [B,H,S,D]).  The kernels read such
+    views in place (fa_*_strided); only layouts they cannot address (non-unit head-dim stride, rows not 16-byte
+    multiples, K and V with different sequence strides) are still copied."""
+    return tuple(t if _fa.strided_ok(t) else t.contiguous() for t in tensors)
+
+
+def _kv_in_place(K, V):
+    K, V = _in_place(K, V)
+    if K.stride(2) != V.stride(2) and K.shape[2] > 1:   # the kernels use one row stride for the K/V pair
+        K, V = K.contiguous(), V.contiguous()
+    return K, V
+
+
 def flash_attention_forward(Q, K, V, is_causal):
-    """Allocate O / LSE and enqueue the forward kernel (M:14-60)."""
+    """Allocate O / LSE and enqueue the forward kernel (M:14-60).  Q, K, V: contiguous, or strided views accepted
+    by _mi355fa.strided_ok with K and V sharing their sequence stride."""
     B, H, S_q, D = Q.shape
     _, _, S_k, _ = K.shape
     O = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
     LSE = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
+    sq, sk, sv = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V)   # keep the ctypes arrays alive over the call
     with torch.cuda.device(Q.device):
-        rc = _fa.lib.fa_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), LSE.data_ptr(),
-                            B, H, S_q, S_k, D, _DTYPES[Q.dtype], int(bool(is_causal)),
-                            1 / (D ** 0.5), _stream())
+        rc = _fa.lib.fa_fwd_strided(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(), LSE.data_ptr(),
+                                    B, H, S_q, S_k, D, _DTYPES[Q.dtype], int(bool(is_causal)),
+                                    1 / (D ** 0.5), _stream())
     _fa.check(rc, "fa_fwd")
     return O, LSE
 
@@ -49,16 +66,18 @@ def flash_attention_backward(Q, K, V, O, dO, LSE, is_causal):
     dV = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
     delta = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
     dt, causal, scale = _DTYPES[Q.dtype], int(bool(is_causal)), 1 / (D ** 0.5)
+    O = O.contiguous()   # the tensor flash_attention_forward returned: a no-op
+    sq, sk, sv, sdo = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V), _fa.strides3(dO)
     with torch.cuda.device(Q.device):
         s = _stream()
-        rc = _fa.lib.fa_bwd_dq(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(),
-                               LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
-                               B, H, S_q, S_k, D, dt, causal, scale, s)
+        rc = _fa.lib.fa_bwd_dq_strided(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(),
+                                       dO.data_ptr(), sdo, LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
+                                       B, H, S_q, S_k, D, dt, causal, scale, s)
         _fa.check(rc, "fa_bwd_dq")
         # same stream, after dQ: the dK/dV kernel reads the delta the dQ kernel wrote (K:376)
-        rc = _fa.lib.fa_bwd_dkv(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(),
-                                LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                                B, H, S_q, S_k, D, dt, causal, scale, s)
+        rc = _fa.lib.fa_bwd_dkv_strided(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, dO.data_ptr(), sdo,
+                                        LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                                        B, H, S_q, S_k, D, dt, causal, scale, s)
         _fa.check(rc, "fa_bwd_dkv")
     return dQ, dK, dV
 
@@ -72,9 +91,8 @@ class FlashAttentionFunction(torch.autograd.Function):
         assert Q.shape[-1] == K.shape[-1] == V.shape[-1]
         assert Q.ndim == 4 and K.ndim == 4 and V.ndim == 4
         assert Q.shape[-1] in (64, 128), "head dim must be 64 or 128"
-        Q_ = Q.contiguous()
-        K_ = K.contiguous()
-        V_ = V.contiguous()
+        (Q_,) = _in_place(Q)          # no copy for views the kernels can read in place (M:138-140 copies them)
+        K_, V_ = _kv_in_place(K, V)
         O, LSE = flash_attention_forward(Q_, K_, V_, is_causal)
         ctx.save_for_backward(Q_, K_, V_, O, LSE)
         ctx.is_causal = is_causal
@@ -83,7 +101,7 @@ class FlashAttentionFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dO):
         Q, K, V, O, LSE = ctx.saved_tensors
-        dO_ = dO.contiguous()
+        (dO_,) = _in_place(dO)
         dQ, dK, dV = flash_attention_backward(Q, K, V, O, dO_, LSE, ctx.is_causal)
         return dQ, dK, dV, None
 

@@ -10,10 +10,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355fa.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FP16, BF16 = 0, 1
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_sp = ctypes.POINTER(ctypes.c_longlong)   # const long long* strides (3 element strides) or NULL
 
 # name -> (restype, argtypes); mirrors include/mi355fa.h one to one
 SIGNATURES = {
@@ -23,6 +24,10 @@ SIGNATURES = {
     "fa_fwd": (_i, [_vp] * 5 + [_i] * 7 + [_f, _vp]),
     "fa_bwd_dq": (_i, [_vp] * 8 + [_i] * 7 + [_f, _vp]),
     "fa_bwd_dkv": (_i, [_vp] * 8 + [_i] * 7 + [_f, _vp]),
+    # strided inputs: (ptr, strides) pairs for q, k, v (and dout), then the contiguous outputs
+    "fa_fwd_strided": (_i, [_vp, _sp] * 3 + [_vp, _vp] + [_i] * 7 + [_f, _vp]),
+    "fa_bwd_dq_strided": (_i, [_vp, _sp] * 3 + [_vp] + [_vp, _sp] + [_vp] * 3 + [_i] * 7 + [_f, _vp]),
+    "fa_bwd_dkv_strided": (_i, [_vp, _sp] * 4 + [_vp] * 4 + [_i] * 7 + [_f, _vp]),
 }
 
 
@@ -44,6 +49,26 @@ def _load():
 
 
 lib = _load()
+
+
+def strides3(t):
+    """ctypes array {batch, head, seq} of element strides for a [B, H, S, D] tensor, or None (= NULL, contiguous)
+    when `t` is contiguous.  Callers must have checked `strided_ok(t)` first."""
+    if t.is_contiguous():
+        return None
+    return (ctypes.c_longlong * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def strided_ok(t):
+    """True if the kernels can read `t` in place: unit head-dim stride, the other strides positive multiples of
+    8 elements (16-byte rows), rows not overlapping, 16-byte aligned base (include/mi355fa.h, strided inputs)."""
+    if t.is_contiguous():
+        return True
+    if t.stride(3) != 1 or t.data_ptr() % 16:
+        return False
+    if t.stride(2) < t.shape[3]:
+        return False
+    return all(t.shape[i] == 1 or (t.stride(i) >= 8 and t.stride(i) % 8 == 0) for i in range(3))
 
 
 def check(rc, what):

@@ -39,6 +39,22 @@ int check_common(const char* fn, int B, int H, int Sq, int Sk, int D, int dtype)
   return 0;
 }
 
+// element strides {batch, head, seq} of a [B, H, S, D] input (NULL = contiguous) -> byte layout
+int make_layout(const char* fn, const long long* st, int H, int S, int D, fa::TensorLayout* out) {
+  if (!st) {
+    *out = fa::contiguous_layout(H, S, D);
+    return 0;
+  }
+  for (int i = 0; i < 3; ++i)
+    if (st[i] < 8 || (st[i] & 7) != 0)
+      return fail(MI355FA_ERR_STRIDE, "%s: strides must be positive multiples of 8 elements", fn);
+  if (st[2] < D) return fail(MI355FA_ERR_STRIDE, "%s: the sequence stride must be at least D elements", fn);
+  if (((long long)S - 1) * st[2] * 2 + 2ll * D > (1ll << 31) - 1)
+    return fail(MI355FA_ERR_STRIDE, "%s: one strided (batch, head) slice exceeds 2^31 bytes", fn);
+  *out = fa::TensorLayout{st[0] * 2, st[1] * 2, (int)(st[2] * 2)};
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -61,43 +77,79 @@ int fa_supported(int D, int dtype) {
   return (D == 64 || D == 128) && (dtype == MI355FA_FP16 || dtype == MI355FA_BF16);
 }
 
-int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
-           int dtype, int causal, float scale, void* stream) {
+int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides, const void* v,
+                   const long long* v_strides, void* o, float* lse, int B, int H, int S_q, int S_k, int D, int dtype,
+                   int causal, float scale, void* stream) {
   if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd");
   if (int rc = check_common("fa_fwd", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd");
   fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  if (int rc = make_layout("fa_fwd", q_strides, H, S_q, D, &p.lq)) return rc;
+  if (int rc = make_layout("fa_fwd", k_strides, H, S_k, D, &p.lk)) return rc;
+  if (int rc = make_layout("fa_fwd", v_strides, H, S_k, D, &p.lv)) return rc;
+  if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_fwd");
   hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_fwd launch");
   return 0;
 }
 
-int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
-              float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream) {
+int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+           int dtype, int causal, float scale, void* stream) {
+  return fa_fwd_strided(q, nullptr, k, nullptr, v, nullptr, o, lse, B, H, S_q, S_k, D, dtype, causal, scale, stream);
+}
+
+int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
+                      const void* v, const long long* v_strides, const void* o, const void* dout,
+                      const long long* dout_strides, const float* lse, void* dq, float* delta, int B, int H, int S_q,
+                      int S_k, int D, int dtype, int causal, float scale, void* stream) {
   if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq");
   if (int rc = check_common("fa_bwd_dq", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
       misaligned(dq) || misaligned(delta))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq");
   fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  if (int rc = make_layout("fa_bwd_dq", q_strides, H, S_q, D, &p.lq)) return rc;
+  if (int rc = make_layout("fa_bwd_dq", k_strides, H, S_k, D, &p.lk)) return rc;
+  if (int rc = make_layout("fa_bwd_dq", v_strides, H, S_k, D, &p.lv)) return rc;
+  if (int rc = make_layout("fa_bwd_dq", dout_strides, H, S_q, D, &p.ldo)) return rc;
+  if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dq");
   hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
   return 0;
 }
 
-int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
-               void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
-               void* stream) {
+int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+              float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream) {
+  return fa_bwd_dq_strided(q, nullptr, k, nullptr, v, nullptr, o, dout, nullptr, lse, dq, delta, B, H, S_q, S_k, D, dtype,
+                           causal, scale, stream);
+}
+
+int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
+                       const void* v, const long long* v_strides, const void* dout, const long long* dout_strides,
+                       const float* lse, const float* delta, void* dk, void* dv, int B, int H, int S_q, int S_k, int D,
+                       int dtype, int causal, float scale, void* stream) {
   if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv");
   if (int rc = check_common("fa_bwd_dkv", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
       misaligned(dk) || misaligned(dv))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv");
   fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  if (int rc = make_layout("fa_bwd_dkv", q_strides, H, S_q, D, &p.lq)) return rc;
+  if (int rc = make_layout("fa_bwd_dkv", k_strides, H, S_k, D, &p.lk)) return rc;
+  if (int rc = make_layout("fa_bwd_dkv", v_strides, H, S_k, D, &p.lv)) return rc;
+  if (int rc = make_layout("fa_bwd_dkv", dout_strides, H, S_q, D, &p.ldo)) return rc;
+  if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dkv");
   hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
   return 0;
+}
+
+int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+               void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+               void* stream) {
+  return fa_bwd_dkv_strided(q, nullptr, k, nullptr, v, nullptr, dout, nullptr, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype,
+                            causal, scale, stream);
 }
 
 }  // extern "C"

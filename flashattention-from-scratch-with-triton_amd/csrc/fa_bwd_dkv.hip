@@ -64,11 +64,18 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   const int kw0 = k0_wg + wave * 32;
   if (pass) __syncthreads();  // the previous pass staged dK / dV in the tile buffers
 
-  const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
+  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK, dV, LSE, delta are contiguous
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
+  const size_t koff = (size_t)bh * p.Sk * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq =
+      make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo =
+      make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, (unsigned)(p.Sq - 1) * do_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk =
+      make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv =
+      make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
   // Row constants of a query tile: wave 0 loads its LSE rows, wave 1 its delta rows, through ONE wave-uniform
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   vec8 kf[C::KS], vf[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
-    const int off = (kw0 + r) * C::ROWB + (2 * ks + h) * 16;
+    const int off = (kw0 + r) * kv_rs + (2 * ks + h) * 16;
     kf[ks] = as_vec8<T>(buf_load16(rk, off));
     if constexpr (FOLD) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
     vf[ks] = as_vec8<T>(buf_load16(rv, off));
@@ -100,8 +107,11 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + RPI * i + lane / C::CPR;
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
+    dma_src[i] = row * q_rs + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
+  // the dO tile has the same lane -> (row, chunk) map; only its row stride may differ (the difference can be
+  // negative: it is added in the VGPR offset, whose sum row*do_rs + chunk is not; the scalar offset is unsigned)
+  const int do_delta = (16 * wave + lane / C::CPR) * (do_rs - q_rs);
   int row_off[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
@@ -122,13 +132,13 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
 
   float cst = 0.f;  // threads 0..63: LSE row, 64..127: delta row
   auto stage_load = [&](int t) __attribute__((always_inline)) {
-    const int soff = t * C::TILE_BYTES;
+    const int soff_q = t * C::BQ * q_rs, soff_do = t * C::BQ * do_rs;
     const int buf = t & 1;
 #pragma unroll
     for (int i = 0; i < C::DMA_PER_MAT; ++i) {
       const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
-      dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
-      dma16(rdo, lds_addr_of(smem + 2 * C::TILE_BYTES + dst), dma_src[i], soff);
+      dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff_q);
+      dma16(rdo, lds_addr_of(smem + 2 * C::TILE_BYTES + dst), dma_src[i] + do_delta + RPI * i * (do_rs - q_rs), soff_do);
     }
     cst = buf_load_f32(rrc, (t * C::BQ + lane) * 4);
   };
@@ -261,7 +271,7 @@ hipError_t launch_bwd_dkv_v3(BwdParams p, int dtype, int causal, hipStream_t s);
 
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
   const int impl = pick_dkv_impl(g_force_dkv, D, p.Sq);
-  if (impl == 3) return launch_bwd_dkv_v3(p, dtype, causal, s);  // one wave per SIMD, 64 keys per wave: A/B only
+  if (impl == 3 && p.all_contiguous(D)) return launch_bwd_dkv_v3(p, dtype, causal, s);  // one wave per SIMD, 64 keys per wave: A/B only
   if (impl == 2) return launch_bwd_dkv_v2(p, D, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);

@@ -77,11 +77,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   const int idx = w - bh * per_bh;
   const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
 
-  const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
+  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK, dV, LSE, delta are contiguous
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
+  const size_t koff = (size_t)bh * p.Sk * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq =
+      make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo =
+      make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, (unsigned)(p.Sq - 1) * do_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk =
+      make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv =
+      make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
   // Row constants of a query tile: the first BQ/64 waves load its LSE rows, the next BQ/64 waves its delta rows,
@@ -104,8 +111,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = (C::BQ / C::NW) * wave + C::RPI * i + lane / C::CPR;
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
+    dma_src[i] = row * q_rs + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
+  // the dO tile has the same lane -> (row, chunk) map; only its row stride may differ (the difference can be
+  // negative: it is added in the VGPR offset, whose sum row*do_rs + chunk is not; the scalar offset is unsigned)
+  const int do_delta = ((C::BQ / C::NW) * wave + lane / C::CPR) * (do_rs - q_rs);
   int row_off[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
@@ -144,12 +154,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
 #ifdef FA_ABLATE_DMA
       if (t > t_start + 1) return;  // keep real (random) data in both buffers: zeros would raise the clock
 #endif
-      const int soff = t * C::TILE_BYTES;
+      const int soff_q = t * C::BQ * q_rs, soff_do = t * C::BQ * do_rs;
 #pragma unroll
       for (int i = 0; i < C::DMA_PER_MAT; ++i) {
         const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * i) * C::ROWB;
-        dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff);
-        dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i], soff);
+        dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff_q);
+        dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i] + do_delta + C::RPI * i * (do_rs - q_rs), soff_do);
       }
       rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4);
     };
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     vec8 kf[C::KS], vf[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      const int off = (kw0 + r) * C::ROWB + (2 * ks + h) * 16;
+      const int off = (kw0 + r) * kv_rs + (2 * ks + h) * 16;
       kf[ks] = as_vec8<T>(buf_load16(rk, off));
       if constexpr (FOLD) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
       vf[ks] = as_vec8<T>(buf_load16(rv, off));

@@ -61,13 +61,20 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   const int qw0 = q0_wg + wave * 32;
   if (pass) __syncthreads();  // the previous pass staged its dQ tile in the K/V buffers
 
-  const size_t qoff = (size_t)bh * p.Sq * C::ROWB, koff = (size_t)bh * p.Sk * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + qoff, (unsigned)p.Sq * C::ROWB);
+  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); O, dQ, LSE, delta are contiguous
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
+  const size_t qoff = (size_t)bh * p.Sq * C::ROWB;
+  const __amdgpu_buffer_rsrc_t rq =
+      make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo =
+      make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, (unsigned)(p.Sq - 1) * do_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)p.o + qoff, (unsigned)p.Sq * C::ROWB);
   const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + koff, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk =
+      make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv =
+      make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
 
@@ -76,10 +83,10 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   float dsum = 0.f;
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
-    const int off = (qw0 + r) * C::ROWB + (2 * ks + h) * 16;
-    qf[ks] = as_vec8<T>(buf_load16(rq, off));
-    dof[ks] = as_vec8<T>(buf_load16(rdo, off));
-    const vec8 of = as_vec8<T>(buf_load16(ro, off));
+    const int col = (2 * ks + h) * 16;
+    qf[ks] = as_vec8<T>(buf_load16(rq, (qw0 + r) * q_rs + col));
+    dof[ks] = as_vec8<T>(buf_load16(rdo, (qw0 + r) * do_rs + col));
+    const vec8 of = as_vec8<T>(buf_load16(ro, (qw0 + r) * C::ROWB + col));
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum = __builtin_fmaf((float)dof[ks][j], (float)of[j], dsum);
   }
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + RPI * i + lane / C::CPR;
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
+    dma_src[i] = row * kv_rs + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
   int row_off[C::KS];  // A-operand row reads (K rows and V rows)
 #pragma unroll
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     for (int i = 0; i < 16; ++i) dqacc[db][i] = 0.f;
 
   auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
-    const int soff = t * C::TILE_BYTES;
+    const int soff = t * C::BN * kv_rs;
 #pragma unroll
     for (int i = 0; i < C::DMA_PER_MAT; ++i) {
       const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
@@ -240,7 +247,8 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v2.hip
 
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  if (pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
+  // family 2 reads contiguous operands only; strided views always take family 1
+  if (p.all_contiguous(D) && pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
     return launch_bwd_dq_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);

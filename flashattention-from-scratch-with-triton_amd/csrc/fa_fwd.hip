@@ -70,13 +70,17 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   const int qw0 = q0_wg + wave * 32;
   if (pass) __syncthreads();  // the previous pass staged its O tile in the K/V buffers
 
-  const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
-  const char* kb = (const char*)p.k + (size_t)bh * p.Sk * C::ROWB;
-  const char* vb = (const char*)p.v + (size_t)bh * p.Sk * C::ROWB;
+  // inputs may be strided views with a contiguous head dim (e.g. a [B,S,H,D] buffer seen as [B,H,S,D]): per-tensor
+  // batch / head byte strides, one row stride for Q and one shared by K and V; O and LSE are contiguous
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int q_rs = p.lq.rs, kv_rs = p.lk.rs;
+  const char* qb = (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh;
+  const char* kb = (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh;
+  const char* vb = (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh;
   char* ob = (char*)p.o + (size_t)bh * p.Sq * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)p.Sk * C::ROWB);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)p.Sq * C::ROWB);
   const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
 
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   vec8 qf[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks)
-    qf[ks] = as_vec8<T>(buf_load16(rq, (qw0 + r) * C::ROWB + (2 * ks + h) * 16));
+    qf[ks] = as_vec8<T>(buf_load16(rq, (qw0 + r) * q_rs + (2 * ks + h) * 16));
 
   // ---- tile schedule ----
   const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + RPI * i + lane / C::CPR;
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane % C::CPR) * 16;
+    dma_src[i] = row * kv_rs + swz_chunk<D>(row, lane % C::CPR) * 16;
   }
   // ---- fragment read addresses (loop invariant) ----
   int k_off[C::KS];
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
 
   auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
-    const int soff = t * C::TILE_BYTES;
+    const int soff = t * C::BN * kv_rs;
 #pragma unroll
     for (int i = 0; i < C::DMA_PER_MAT; ++i) {
       const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
@@ -369,7 +373,8 @@ static hipError_t launch(const FwdParams& p, hipStream_t s) {
 hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v2.hip
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  if (pick_fwd_dq_impl(g_force_fwd, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
+  // family 2 reads contiguous operands only; strided views always take family 1
+  if (p.all_contiguous(D) && pick_fwd_dq_impl(g_force_fwd, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
     return launch_fwd_v2(p, dtype, causal, s);
   p.nq_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.nq_tiles, (long)p.B * p.H);

@@ -4,6 +4,17 @@
 
 namespace fa {
 
+// Byte strides of one [B, H, S, D] INPUT operand whose D dimension is contiguous: batch, head, row.
+// Outputs (O, LSE, dQ, delta, dK, dV) are always contiguous.
+struct TensorLayout {
+  long long sb, sh;
+  int rs;
+  bool contiguous(int H, int S, int D) const { return rs == 2 * D && sh == (long long)S * rs && sb == (long long)H * sh; }
+};
+inline TensorLayout contiguous_layout(int H, int S, int D) {
+  return TensorLayout{(long long)H * S * D * 2, (long long)S * D * 2, D * 2};
+}
+
 struct FwdParams {
   const void* q;
   const void* k;
@@ -15,6 +26,8 @@ struct FwdParams {
   int nq_tiles;  // filled by the launcher
   void* dbg;     // diagnostic builds (-DFA_STAMPS) only: cycle-stamp buffer, else unused
   int pair;      // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
+  TensorLayout lq, lk, lv;  // K and V share their row stride (checked by the C ABI)
+  bool all_contiguous(int D) const { return lq.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D); }
 };
 
 struct BwdParams {
@@ -33,6 +46,10 @@ struct BwdParams {
   int n_tiles;      // filled by the launcher
   void* dbg;        // diagnostic builds (-DFA_STAMPS) only
   int pair;         // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
+  TensorLayout lq, lk, lv, ldo;  // K and V share their row stride (checked by the C ABI); O is contiguous
+  bool all_contiguous(int D) const {
+    return lq.contiguous(H, Sq, D) && ldo.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
+  }
 };
 
 // ---- schedule selection (the counterpart of the reference's autotune key (S_q, S_k, D, is_causal),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355FA_ABI_VERSION 1
+#define MI355FA_ABI_VERSION 2
 
 /* dtype codes */
 #define MI355FA_FP16 0
@@ -49,6 +49,8 @@ extern "C" {
 #define MI355FA_ERR_HEAD_DIM (-3)  /* D not in {64, 128} */
 #define MI355FA_ERR_DTYPE (-4)     /* dtype not MI355FA_FP16 / MI355FA_BF16 */
 #define MI355FA_ERR_ALIGN (-5)     /* a pointer is not 16-byte aligned */
+#define MI355FA_ERR_STRIDE (-6)    /* a stride is not a positive multiple of 8 elements, K and V differ in their
+                                      sequence stride, or a strided slice exceeds 2^31 bytes */
 
 int fa_abi_version(void);
 
@@ -74,6 +76,30 @@ int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout,
                const float* lse, const float* delta, void* dk, void* dv,
                int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
                void* stream);
+
+/* ---- strided inputs -------------------------------------------------------------------------
+ * The reference's binding makes every input contiguous first (code/My_FlashAttention_optimized.py:138-140,156 --
+ * a 64 MiB copy per tensor at the headline size whenever Q/K/V are transposed views of a fused projection).
+ * The *_strided entry points read such views in place.  Each INPUT operand [B, H, S, D] gets an array of three
+ * ELEMENT strides {batch, head, sequence}; the head-dim stride is 1.  NULL = contiguous.  Example: a [B, S, H, D]
+ * buffer viewed as [B, H, S, D] has {S*H*D, D, H*D}.  Every stride must be a positive multiple of 8 elements
+ * (16-byte rows) and K, V must share their sequence stride.  Outputs (o, lse, dq, delta, dk, dv) and the `o`
+ * argument of fa_bwd_dq_strided (the tensor fa_fwd* wrote) stay contiguous.  Everything else is as above.
+ */
+int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
+                   const void* v, const long long* v_strides, void* o, float* lse,
+                   int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
+
+int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
+                      const void* v, const long long* v_strides, const void* o,
+                      const void* dout, const long long* dout_strides,
+                      const float* lse, void* dq, float* delta,
+                      int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
+
+int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
+                       const void* v, const long long* v_strides, const void* dout, const long long* dout_strides,
+                       const float* lse, const float* delta, void* dk, void* dv,
+                       int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
 
 #ifdef __cplusplus
 }

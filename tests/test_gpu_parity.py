@@ -290,3 +290,62 @@ def test_errors_raise():
         M.flash_attention(y, y, y)                       # dtype (M:134)
     with pytest.raises(RuntimeError, match="head dim"):
         M.flash_attention_forward(x, x, x, False)        # the C ABI rejects it too, before any launch
+
+
+# ---------------------------------------------------------------- (5) strided inputs
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
+@pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
+def test_strided_views_are_read_in_place_and_bit_identical(D, causal, dtype, impl):
+    """Q/K/V as transposed views of one fused [B, S, 3, H, D] projection output, dO as a view of a [B, S, H, D]
+    buffer: the kernels read them in place (the reference copies, M:138-140,156) and must give exactly the bits
+    they give on contiguous copies of the same data -- same arithmetic, different addressing."""
+    M = _host()
+    import _mi355fa as fa
+    if impl == 2:   # strided views always take family 1 for forward / dQ: pin it for the contiguous twin as well
+        fa.lib.fa_debug_force_impl(1, 1, 2)
+    B, H, Sq = 2, 3, 333
+    torch.manual_seed(3)
+    qkv = torch.randn(B, Sq, 3, H, D, device="cuda", dtype=dtype)
+    Qv, Kv, Vv = (qkv[:, :, i].transpose(1, 2) for i in range(3))            # [B, H, S, D] views
+    dOv = torch.randn(B, Sq, H, D, device="cuda", dtype=dtype).transpose(1, 2)
+    for t in (Qv, Kv, Vv, dOv):
+        assert not t.is_contiguous() and fa.strided_ok(t)
+    # launcher level: views straight in
+    O1, L1 = M.flash_attention_forward(Qv, Kv, Vv, causal)
+    O2, L2 = M.flash_attention_forward(Qv.contiguous(), Kv.contiguous(), Vv.contiguous(), causal)
+    assert torch.equal(O1, O2) and torch.equal(L1, L2)
+    g1 = M.flash_attention_backward(Qv, Kv, Vv, O1, dOv, L1, causal)
+    g2 = M.flash_attention_backward(Qv.contiguous(), Kv.contiguous(), Vv.contiguous(), O2, dOv.contiguous(), L2, causal)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    # autograd level: gradients flow back to the fused buffer; no .contiguous() copy of the views is saved
+    x = qkv.clone().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    o = M.flash_attention(q, k, v, causal)
+    saved = o.grad_fn.saved_tensors
+    assert saved[0].data_ptr() == q.data_ptr() and saved[1].data_ptr() == k.data_ptr()   # views, not copies
+    o.backward(dOv)
+    ref = torch.stack([g.transpose(1, 2) for g in g1], dim=2)                # [B, S, 3, H, D]
+    assert torch.equal(x.grad, ref)
+    # and against the fp64 oracle, like every other case
+    gt = fo.attention_fp64(Qv.cpu(), Kv.cpu(), Vv.cpu(), dOv.cpu(), causal)
+    tol = 1e-3 if dtype == F16 else 5e-3
+    for name, got in zip(("O", "dQ", "dK", "dV"), (O1,) + tuple(g1)):
+        assert fo.rel_fro(gt[name], got.cpu()) < tol, name
+
+
+def test_layouts_the_kernels_cannot_address_are_copied_not_misread():
+    """Unit head-dim stride missing, or K and V with different sequence strides: the host copies (like the
+    reference); results equal the contiguous ones."""
+    M = _host()
+    torch.manual_seed(4)
+    B, H, S, D = 1, 2, 200, 64
+    Q = torch.randn(B, H, S, D, device="cuda", dtype=F16)
+    K = torch.randn(B, S, H, D, device="cuda", dtype=F16).transpose(1, 2)            # bshd view
+    V = torch.randn(B, H, S, D, device="cuda", dtype=F16)                             # contiguous: strides differ from K
+    Qt = torch.randn(B, H, D, S, device="cuda", dtype=F16).transpose(2, 3)            # head dim not unit stride
+    for q in (Q, Qt):
+        o = M.flash_attention(q, K, V, True)
+        o2 = M.flash_attention(q.contiguous(), K.contiguous(), V.contiguous(), True)
+        assert torch.equal(o, o2)

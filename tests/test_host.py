@@ -20,7 +20,8 @@ def _header_functions():
 
 
 def test_header_declares_expected_entry_points():
-    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dq", "fa_fwd", "fa_last_error", "fa_supported"]
+    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_strided", "fa_bwd_dq", "fa_bwd_dq_strided",
+                                   "fa_fwd", "fa_fwd_strided", "fa_last_error", "fa_supported"]
 
 
 def test_library_exports_every_declared_symbol():
@@ -29,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(raw, name), name
         assert name in fa.SIGNATURES, "python binding misses " + name
-    assert fa.lib.fa_abi_version() == 1
+    assert fa.lib.fa_abi_version() == 2
     assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
@@ -50,6 +51,32 @@ def test_argument_errors_are_rejected_before_launch():
     assert L.fa_bwd_dkv(p, p, p, p, p, p, p, p, 1, 1, 8, 8, 65, 1, 0, 0.125, None) == -3
     with pytest.raises(RuntimeError, match="head dim"):
         fa.check(-3, "fa_fwd")
+    # strided entry points: element strides {batch, head, seq}; NULL = contiguous
+    S3 = ctypes.c_longlong * 3
+    ok = S3(8 * 2 * 64, 64, 2 * 64)          # a [B=1, S=8, H=2, D=64] buffer seen as [B, H, S, D]
+    args = (1, 2, 8, 8, 64, 1, 0, 0.125, None)
+    assert L.fa_fwd_strided(None, ok, p, ok, p, ok, p, p, *args) == -1
+    assert L.fa_fwd_strided(p, S3(1024, 64, 100), p, ok, p, ok, p, p, *args) == -6      # 100 is not a multiple of 8
+    assert b"multiples of 8" in L.fa_last_error()
+    assert L.fa_fwd_strided(p, ok, p, ok, p, S3(1024, 64, 256), p, p, *args) == -6       # K and V row strides differ
+    assert b"K and V" in L.fa_last_error()
+    assert L.fa_fwd_strided(p, S3(1024, 64, 32), p, ok, p, ok, p, p, *args) == -6        # rows would overlap
+    assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, p, S3(0, 64, 128), p, p, p, *args) == -6
+    assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, None, *args) == -1
+
+
+def test_strided_ok_accepts_bshd_views_and_rejects_the_rest():
+    import _mi355fa as fa
+    x = torch.zeros(2, 16, 4, 64, dtype=torch.float16)            # [B, S, H, D]
+    v = x.transpose(1, 2)                                          # [B, H, S, D] view
+    assert not v.is_contiguous() and fa.strided_ok(v)
+    assert list(fa.strides3(v)) == [16 * 4 * 64, 64, 4 * 64]
+    assert fa.strides3(x) is None and fa.strided_ok(x)
+    assert not fa.strided_ok(torch.zeros(2, 4, 64, 16, dtype=torch.float16).transpose(2, 3))   # head dim not unit stride
+    assert not fa.strided_ok(torch.zeros(2, 4, 16, 68, dtype=torch.float16)[..., :64][..., 2:])  # odd row pitch / offset
+    qkv = torch.zeros(2, 16, 3, 4, 64, dtype=torch.float16)       # fused projection output [B, S, 3, H, D]
+    q, k, vv = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    assert all(fa.strided_ok(t) for t in (q, k, vv)) and k.stride(2) == vv.stride(2)
 
 
 def test_python_surface_matches_reference():

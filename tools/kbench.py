@@ -42,6 +42,8 @@ a = ap.parse_args()
 def load(path):
     lib = ctypes.CDLL(path if os.path.isabs(path) else os.path.join(ROOT, path))
     for name, (res, args) in host.SIGNATURES.items():
+        if not hasattr(lib, name):   # an older A/B build (e.g. before the strided entry points)
+            continue
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     if a.impl and hasattr(lib, "fa_debug_force_impl"):
