@@ -20,10 +20,36 @@ import torch.nn.functional as F
 import _mi355fa as _fa
 
 _DTYPES = {torch.float16: _fa.FP16, torch.bfloat16: _fa.BF16}
+_fwd, _bwd_dq, _bwd_dkv = _fa.lib.fa_fwd_strided, _fa.lib.fa_bwd_dq_strided, _fa.lib.fa_bwd_dkv_strided
 
 
-def _stream():
+try:   # the raw hipStream_t of PyTorch's current stream without building a torch.cuda.Stream object (~3 us per call)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover - older / newer PyTorch without the private accessor
+    _raw_stream = None
+
+
+def _stream(index=None):
+    if _raw_stream is not None and index is not None:
+        return _raw_stream(index)
     return torch.cuda.current_stream().cuda_stream
+
+
+class _OnDevice:
+    """`with torch.cuda.device(d)` only when `d` is not already current (the context manager costs ~5 us per call,
+    which is most of the host time at the reference's small benchmark shapes)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        self.ctx = None if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 def _in_place(*tensors):
@@ -49,11 +75,11 @@ def flash_attention_forward(Q, K, V, is_causal):
     O = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
     LSE = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
     sq, sk, sv = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V)   # keep the ctypes arrays alive over the call
-    with torch.cuda.device(Q.device):
-        rc = _fa.lib.fa_fwd_strided(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(), LSE.data_ptr(),
-                                    B, H, S_q, S_k, D, _DTYPES[Q.dtype], int(bool(is_causal)),
-                                    1 / (D ** 0.5), _stream())
-    _fa.check(rc, "fa_fwd")
+    with _OnDevice(Q.device):
+        rc = _fwd(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(), LSE.data_ptr(),
+                  B, H, S_q, S_k, D, _DTYPES[Q.dtype], 1 if is_causal else 0, 1 / (D ** 0.5), _stream(Q.device.index))
+    if rc:
+        _fa.check(rc, "fa_fwd")
     return O, LSE
 
 
@@ -65,20 +91,23 @@ def flash_attention_backward(Q, K, V, O, dO, LSE, is_causal):
     dK = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
     dV = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
     delta = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
-    dt, causal, scale = _DTYPES[Q.dtype], int(bool(is_causal)), 1 / (D ** 0.5)
-    O = O.contiguous()   # the tensor flash_attention_forward returned: a no-op
+    dt, causal, scale = _DTYPES[Q.dtype], 1 if is_causal else 0, 1 / (D ** 0.5)
+    if not O.is_contiguous():   # normally the tensor flash_attention_forward returned
+        O = O.contiguous()
     sq, sk, sv, sdo = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V), _fa.strides3(dO)
-    with torch.cuda.device(Q.device):
-        s = _stream()
-        rc = _fa.lib.fa_bwd_dq_strided(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(),
-                                       dO.data_ptr(), sdo, LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
-                                       B, H, S_q, S_k, D, dt, causal, scale, s)
-        _fa.check(rc, "fa_bwd_dq")
+    with _OnDevice(Q.device):
+        s = _stream(Q.device.index)
+        rc = _bwd_dq(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(),
+                     dO.data_ptr(), sdo, LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
+                     B, H, S_q, S_k, D, dt, causal, scale, s)
+        if rc:
+            _fa.check(rc, "fa_bwd_dq")
         # same stream, after dQ: the dK/dV kernel reads the delta the dQ kernel wrote (K:376)
-        rc = _fa.lib.fa_bwd_dkv_strided(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, dO.data_ptr(), sdo,
-                                        LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                                        B, H, S_q, S_k, D, dt, causal, scale, s)
-        _fa.check(rc, "fa_bwd_dkv")
+        rc = _bwd_dkv(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, dO.data_ptr(), sdo,
+                      LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                      B, H, S_q, S_k, D, dt, causal, scale, s)
+        if rc:
+            _fa.check(rc, "fa_bwd_dkv")
     return dQ, dK, dV
 
 
@@ -91,8 +120,11 @@ class FlashAttentionFunction(torch.autograd.Function):
         assert Q.shape[-1] == K.shape[-1] == V.shape[-1]
         assert Q.ndim == 4 and K.ndim == 4 and V.ndim == 4
         assert Q.shape[-1] in (64, 128), "head dim must be 64 or 128"
-        (Q_,) = _in_place(Q)          # no copy for views the kernels can read in place (M:138-140 copies them)
-        K_, V_ = _kv_in_place(K, V)
+        if Q.is_contiguous() and K.is_contiguous() and V.is_contiguous():
+            Q_, K_, V_ = Q, K, V
+        else:                         # no copy for views the kernels can read in place (M:138-140 copies them)
+            (Q_,) = _in_place(Q)
+            K_, V_ = _kv_in_place(K, V)
         O, LSE = flash_attention_forward(Q_, K_, V_, is_causal)
         ctx.save_for_backward(Q_, K_, V_, O, LSE)
         ctx.is_causal = is_causal
@@ -101,7 +133,7 @@ class FlashAttentionFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dO):
         Q, K, V, O, LSE = ctx.saved_tensors
-        (dO_,) = _in_place(dO)
+        dO_ = dO if dO.is_contiguous() else _in_place(dO)[0]
         dQ, dK, dV = flash_attention_backward(Q, K, V, O, dO_, LSE, ctx.is_causal)
         return dQ, dK, dV, None
 
