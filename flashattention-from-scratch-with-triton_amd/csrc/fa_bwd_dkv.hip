@@ -267,11 +267,9 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 }
 
 hipError_t launch_bwd_dkv_v2(BwdParams p, int D, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v2.hip
-hipError_t launch_bwd_dkv_v3(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v3.hip
 
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
   const int impl = pick_dkv_impl(g_force_dkv, D, p.Sq);
-  if (impl == 3 && p.all_contiguous(D)) return launch_bwd_dkv_v3(p, dtype, causal, s);  // one wave per SIMD, 64 keys per wave: A/B only
   if (impl == 2) return launch_bwd_dkv_v2(p, D, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);

@@ -349,3 +349,41 @@ def test_layouts_the_kernels_cannot_address_are_copied_not_misread():
         o = M.flash_attention(q, K, V, True)
         o2 = M.flash_attention(q.contiguous(), K.contiguous(), V.contiguous(), True)
         assert torch.equal(o, o2)
+
+
+def test_step_is_hip_graph_capturable():
+    """The launchers only enqueue on the caller's stream (no allocation, no synchronisation, no host-side state):
+    a whole fwd+bwd step can be captured into a hipGraph and replayed with identical results."""
+    M = _host()
+    torch.manual_seed(11)
+    Q, K, V, dO = (torch.randn(2, 4, 512, 64, device="cuda", dtype=BF16) for _ in range(4))
+    for t in (Q, K, V):
+        t.requires_grad_(True)
+    out = {}
+
+    def step():
+        o = M.flash_attention(Q, K, V, True)
+        o.backward(dO)
+        out["o"], out["dq"], out["dk"], out["dv"] = o.detach(), Q.grad, K.grad, V.grad
+        Q.grad = None
+        K.grad = None
+        V.grad = None
+
+    step()
+    eager = {k: v.clone() for k, v in out.items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    captured = dict(out)                      # static output tensors of the captured step
+    for t in captured.values():
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in eager:
+        assert torch.equal(eager[k], captured[k]), k
