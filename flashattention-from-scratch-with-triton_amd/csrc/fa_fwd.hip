@@ -263,12 +263,28 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   // is exactly as good as the true one (softmax is shift invariant).  Otherwise (always the first tile: m = -inf
   // gives p = +inf; afterwards only if scores jump by more than ~2^8) NOTHING has been committed: return false
   // and the caller redoes the tile on the exact path.
-  auto tile_lazy = [&](int t) __attribute__((always_inline)) -> bool {
+  // MASKED = true: the same for a tile on the causal diagonal or the ragged tail -- dead scores become -inf (p = 0),
+  // key blocks no row of the wave can see are skipped.  A wave whose first visible tile is masked arrives here with
+  // m = -inf, overflows by construction and takes the exact path once.
+  auto tile_lazy = [&](int t, auto masked_tag) __attribute__((always_inline)) -> bool {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
     const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
+    const int s0 = t * C::BN;
+    bool use[2] = {true, true};
+    if constexpr (MASKED) {
+      if (CAUSAL) {
+        use[0] = s0 <= qw0;
+        use[1] = s0 + 32 <= qw0;
+      }
+      use[0] = use[0] && s0 < p.Sk;
+      use[1] = use[1] && s0 + 32 < p.Sk;
+      if (!use[0] && !use[1]) return true;  // nothing of this tile is visible to the wave
+    }
     f32x16 sacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
+      if (MASKED && !use[b]) continue;
 #pragma unroll
       for (int i = 0; i < 16; ++i) sacc[b][i] = FOLD ? negm[i] : 0.f;
 #pragma unroll
@@ -280,18 +296,27 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     const float mc = m * c2;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b) {
+      if (MASKED && !use[b]) continue;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pe = __builtin_amdgcn_exp2f(FOLD ? sacc[b][i] : __builtin_fmaf(sacc[b][i], c2, -mc));
+        float x = FOLD ? sacc[b][i] : __builtin_fmaf(sacc[b][i], c2, -mc);
+        if constexpr (MASKED) {
+          const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool dead = (CAUSAL && key > qw0 + r) || key >= p.Sk;
+          x = dead ? -INFINITY : x;
+        }
+        const float pe = __builtin_amdgcn_exp2f(x);
         sacc[b][i] = pe;
         ls[i & 3] += pe;
       }
+    }
     const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
     if (__builtin_amdgcn_ballot_w64(!(lsum <= kLazySumMax)) != 0) return false;
     l += lsum;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
+      if (MASKED && !use[b]) continue;
       const vec8 pf0 = pack8<T, 0>(sacc[b]);
       const vec8 pf1 = pack8<T, 1>(sacc[b]);
 #pragma unroll
@@ -306,16 +331,6 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     return true;
   };
 
-  // one loop iteration: prefetch tile t+1 to registers, compute tile t, park t+1 in the other buffer
-  auto iter = [&](int t, auto buf_tag, auto masked_tag) {
-    constexpr int BUF = decltype(buf_tag)::value;
-    const bool more = t + 1 < ntiles;
-    if (more) dma_tile(t + 1, BUF >= 0 ? (BUF ^ 1) : ((t + 1) & 1));
-    tile(t, buf_tag, masked_tag);
-    tile_sync();
-  };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
   using BR = std::integral_constant<int, -1>;
 
   // ---- main loop: one barrier per tile; every wave runs exactly ntiles iterations ----
@@ -338,14 +353,20 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
     prefetched = false;
     for (; t < nfull; ++t) {
       if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-      if (!tile_lazy(t)) {
+      if (!tile_lazy(t, std::false_type{})) {
         prefetched = true;
         break;
       }
       tile_sync();
     }
   }
-  for (; t < ntiles; ++t) iter(t, BR{}, std::true_type{});
+  // masked tiles (causal diagonal, ragged tail): lazy first, the exact path only if the stale max cannot be used
+  for (; t < ntiles; ++t) {
+    if (!prefetched && t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
+    prefetched = false;
+    if (!tile_lazy(t, std::true_type{})) tile(t, BR{}, std::true_type{});
+    tile_sync();
+  }
 
   // ---- epilogue ----
   const float lt = half_sum(l);
