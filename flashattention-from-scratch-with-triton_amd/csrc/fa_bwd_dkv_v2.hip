@@ -479,7 +479,11 @@ static hipError_t launch2(const BwdParams& p, hipStream_t s) {
   using C = Dkv2Cfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dkv2_kernel<D, T, CAUSAL>;
-  static const int pad = getenv("FA_LDS_PAD") ? atoi(getenv("FA_LDS_PAD")) : 0;  // diagnostic: force 1 workgroup per CU
+#ifdef FA_STAMPS   // diagnostic builds only: extra LDS per workgroup forces one workgroup per CU (tools/stamps_dkv.py)
+  static const int pad = getenv("FA_LDS_PAD") ? atoi(getenv("FA_LDS_PAD")) : 0;
+#else
+  constexpr int pad = 0;
+#endif
   if (C::LDS_BYTES + pad > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + pad);
     if (e != hipSuccess) return e;
