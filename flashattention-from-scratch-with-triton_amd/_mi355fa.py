@@ -56,19 +56,24 @@ def strides3(t):
     when `t` is contiguous.  Callers must have checked `strided_ok(t)` first."""
     if t.is_contiguous():
         return None
-    return (ctypes.c_longlong * 3)(t.stride(0), t.stride(1), t.stride(2))
+    # a size-1 dimension may carry any stride in PyTorch: it is never multiplied by a non-zero index
+    return (ctypes.c_longlong * 3)(*(t.stride(i) if t.shape[i] > 1 else 0 for i in range(2)),
+                                   t.stride(2) if t.shape[2] > 1 else t.shape[3])
 
 
 def strided_ok(t):
-    """True if the kernels can read `t` in place: unit head-dim stride, the other strides positive multiples of
-    8 elements (16-byte rows), rows not overlapping, 16-byte aligned base (include/mi355fa.h, strided inputs)."""
+    """True if the kernels can read `t` in place: unit head-dim stride, the other strides multiples of 8 elements
+    (16-byte rows; batch / head may be 0), rows not overlapping, 16-byte aligned base (include/mi355fa.h)."""
     if t.is_contiguous():
         return True
     if t.stride(3) != 1 or t.data_ptr() % 16:
         return False
     if t.stride(2) < t.shape[3]:
         return False
-    return all(t.shape[i] == 1 or (t.stride(i) >= 8 and t.stride(i) % 8 == 0) for i in range(3))
+    if t.shape[2] > 1 and t.stride(2) % 8:
+        return False
+    # batch / head strides may be 0: an expanded K/V shared by several heads is read in place
+    return all(t.shape[i] == 1 or (t.stride(i) >= 0 and t.stride(i) % 8 == 0) for i in range(2))
 
 
 def check(rc, what):

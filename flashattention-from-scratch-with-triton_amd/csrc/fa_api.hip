@@ -45,9 +45,10 @@ int make_layout(const char* fn, const long long* st, int H, int S, int D, fa::Te
     *out = fa::contiguous_layout(H, S, D);
     return 0;
   }
+  // batch / head strides may be 0 (an expanded K/V shared by several heads, MQA / GQA style); rows must not overlap
   for (int i = 0; i < 3; ++i)
-    if (st[i] < 8 || (st[i] & 7) != 0)
-      return fail(MI355FA_ERR_STRIDE, "%s: strides must be positive multiples of 8 elements", fn);
+    if (st[i] < 0 || (st[i] & 7) != 0)
+      return fail(MI355FA_ERR_STRIDE, "%s: strides must be non-negative multiples of 8 elements", fn);
   if (st[2] < D) return fail(MI355FA_ERR_STRIDE, "%s: the sequence stride must be at least D elements", fn);
   if (((long long)S - 1) * st[2] * 2 + 2ll * D > (1ll << 31) - 1)
     return fail(MI355FA_ERR_STRIDE, "%s: one strided (batch, head) slice exceeds 2^31 bytes", fn);

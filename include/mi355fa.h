@@ -49,7 +49,7 @@ extern "C" {
 #define MI355FA_ERR_HEAD_DIM (-3)  /* D not in {64, 128} */
 #define MI355FA_ERR_DTYPE (-4)     /* dtype not MI355FA_FP16 / MI355FA_BF16 */
 #define MI355FA_ERR_ALIGN (-5)     /* a pointer is not 16-byte aligned */
-#define MI355FA_ERR_STRIDE (-6)    /* a stride is not a positive multiple of 8 elements, K and V differ in their
+#define MI355FA_ERR_STRIDE (-6)    /* a stride is negative or not a multiple of 8 elements, K and V differ in their
                                       sequence stride, or a strided slice exceeds 2^31 bytes */
 
 int fa_abi_version(void);
@@ -82,8 +82,9 @@ int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout,
  * a 64 MiB copy per tensor at the headline size whenever Q/K/V are transposed views of a fused projection).
  * The *_strided entry points read such views in place.  Each INPUT operand [B, H, S, D] gets an array of three
  * ELEMENT strides {batch, head, sequence}; the head-dim stride is 1.  NULL = contiguous.  Example: a [B, S, H, D]
- * buffer viewed as [B, H, S, D] has {S*H*D, D, H*D}.  Every stride must be a positive multiple of 8 elements
- * (16-byte rows) and K, V must share their sequence stride.  Outputs (o, lse, dq, delta, dk, dv) and the `o`
+ * buffer viewed as [B, H, S, D] has {S*H*D, D, H*D}.  Every stride must be a multiple of 8 elements (16-byte rows);
+ * the batch and head strides may be 0 (one K/V head expanded over several query heads), the sequence stride must be
+ * at least D, and K, V must share their sequence stride.  Outputs (o, lse, dq, delta, dk, dv) and the `o`
  * argument of fa_bwd_dq_strided (the tensor fa_fwd* wrote) stay contiguous.  Everything else is as above.
  */
 int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,

@@ -387,3 +387,32 @@ def test_step_is_hip_graph_capturable():
     torch.cuda.synchronize()
     for k in eager:
         assert torch.equal(eager[k], captured[k]), k
+
+
+@pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
+def test_expanded_kv_heads_are_read_in_place(dtype):
+    """One K/V head shared by all query heads (MQA-style `expand`, head stride 0): read in place, bit-identical to the
+    materialised copy; autograd sums the per-head dK / dV back into the shared head."""
+    M = _host()
+    import _mi355fa as fa
+    torch.manual_seed(8)
+    B, H, S, D = 2, 4, 300, 64
+    q = torch.randn(B, H, S, D, device="cuda", dtype=dtype, requires_grad=True)
+    k1 = torch.randn(B, 1, S, D, device="cuda", dtype=dtype, requires_grad=True)
+    v1 = torch.randn(B, 1, S, D, device="cuda", dtype=dtype, requires_grad=True)
+    dO = torch.randn(B, H, S, D, device="cuda", dtype=dtype)
+    k, v = k1.expand(B, H, S, D), v1.expand(B, H, S, D)
+    assert k.stride(1) == 0 and fa.strided_ok(k) and fa.strided_ok(v)
+    o = M.flash_attention(q, k, v, True)
+    assert o.grad_fn.saved_tensors[1].data_ptr() == k1.data_ptr()          # the expanded view, not a copy
+    o.backward(dO)
+    q2 = q.detach().clone().requires_grad_(True)
+    k2 = k.detach().contiguous().requires_grad_(True)
+    v2 = v.detach().contiguous().requires_grad_(True)
+    o2 = M.flash_attention(q2, k2, v2, True)
+    o2.backward(dO)
+    assert torch.equal(o, o2) and torch.equal(q.grad, q2.grad)
+    # the shared head receives the sum over query heads (fp32 sum of the 16-bit per-head gradients, rounded once)
+    for g1, g2 in ((k1.grad, k2.grad), (v1.grad, v2.grad)):
+        ref = g2.float().sum(dim=1, keepdim=True)
+        assert (g1.float() - ref).abs().max() <= 2e-2 * ref.abs().max()

@@ -61,7 +61,7 @@ def test_argument_errors_are_rejected_before_launch():
     assert L.fa_fwd_strided(p, ok, p, ok, p, S3(1024, 64, 256), p, p, *args) == -6       # K and V row strides differ
     assert b"K and V" in L.fa_last_error()
     assert L.fa_fwd_strided(p, S3(1024, 64, 32), p, ok, p, ok, p, p, *args) == -6        # rows would overlap
-    assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, p, S3(0, 64, 128), p, p, p, *args) == -6
+    assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, p, S3(-8, 64, 128), p, p, p, *args) == -6   # negative stride
     assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, None, *args) == -1
 
 
@@ -77,6 +77,8 @@ def test_strided_ok_accepts_bshd_views_and_rejects_the_rest():
     qkv = torch.zeros(2, 16, 3, 4, 64, dtype=torch.float16)       # fused projection output [B, S, 3, H, D]
     q, k, vv = (qkv[:, :, i].transpose(1, 2) for i in range(3))
     assert all(fa.strided_ok(t) for t in (q, k, vv)) and k.stride(2) == vv.stride(2)
+    kv = torch.zeros(2, 1, 16, 64, dtype=torch.float16).expand(2, 4, 16, 64)     # one K/V head shared by four query heads
+    assert fa.strided_ok(kv) and list(fa.strides3(kv)) == [16 * 64, 0, 64]
 
 
 def test_python_surface_matches_reference():
