@@ -5,6 +5,8 @@
 // softmax state, l sums the un-rounded p (K:111), P is rounded to the input dtype for
 // P@V (K:115), O = o / l cast on store (K:120-123), LSE = m + ln(l) (K:126),
 // top-left aligned causal mask (K:102), keys >= S_k masked (K:94).
+// Deviations inside the stated tolerance: the scale multiplies the fp32 accumulator once (fp16) or is folded into the
+// resident Q fragments (bf16, fa_common.h kFoldScale); the rescale is deferred / lazy (tile(), tile_lazy()).
 //
 // Work decomposition (CDNA4-first, not the reference's 64x64 Triton tiles):
 //   workgroup = 4 waves = 128 query rows of one (batch, head); wave = 32 query rows.
