@@ -2,9 +2,11 @@
 lengths around every tile boundary the kernels use (32 / 64 / 128 / 256) -- each checked against the fp64 oracle and run
 twice for bit-identical results (the kernels use no atomics; a difference is a race, cf. DESIGN.md "raw tile barrier").
 
-Tolerances as in test_gpu_parity.py: fp16 relFro < 1e-3; bf16 relFro < max(2 x PyTorch's own bf16 SDPA, 4e-3).
+Tolerances as in test_gpu_parity.py: fp16 relFro < max(1e-3, 1.5 x the reference algorithm's own error on the same
+inputs); bf16 relFro < max(2 x PyTorch's own bf16 SDPA, 4e-3).
 One large-grid case per dtype exercises the occupancy-dependent schedule choices (three workgroups per CU).
 """
+import os
 import random
 
 import pytest
@@ -18,7 +20,8 @@ pytestmark = pytest.mark.gpu
 F16, BF16 = torch.float16, torch.bfloat16
 
 
-def _cases(n=28, seed=20260101):
+def _cases(n=int(os.environ.get("FA_FUZZ_CASES", "28")), seed=int(os.environ.get("FA_FUZZ_SEED", "20260101"))):
+    """28 cases by default; FA_FUZZ_CASES / FA_FUZZ_SEED widen the hunt (e.g. 400 cases in about a minute)."""
     rng = random.Random(seed)
     edges = [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 191, 192, 255, 256, 257, 320, 383, 384, 500, 512, 640, 777]
     out = []
@@ -50,9 +53,10 @@ def test_random_shape_against_fp64_and_itself(case):
     gt = fo.attention_fp64(Q, K, V, dO, causal)
     r = _run(Q, K, V, dO, causal)
     r2 = _run(Q, K, V, dO, causal)
-    peer = None
-    if dtype == BF16:
-        peer = dict(zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))
+    # what the reference's own algorithm (its rounding points restated on the CPU) / PyTorch's 16-bit SDPA reach on
+    # the same inputs: at degenerate sizes (two rows, gradients that are pure cancellation) even those sit at 2e-2
+    peer = fo.fwd_bwd_tiled(Q, K, V, dO, causal) if dtype == F16 else dict(
+        zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))
     for k in ("O", "dQ", "dK", "dV"):
         assert torch.equal(r[k], r2[k]), (k, "not deterministic")
         out = r[k].cpu()
@@ -62,7 +66,7 @@ def test_random_shape_against_fp64_and_itself(case):
             continue
         err = fo.rel_fro(gt[k], out)
         if dtype == F16:
-            assert err < 1e-3, (k, err)
+            assert err < max(1.5 * fo.rel_fro(gt[k], peer[k]), 1e-3), (k, err)
         else:
             assert err < max(2 * fo.rel_fro(gt[k], peer[k]), 4e-3), (k, err)
 
