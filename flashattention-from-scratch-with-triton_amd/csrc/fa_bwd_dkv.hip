@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   };
 
   if (p.Sq % C::BQ != 0) {  // a ragged last query tile must not expose uninitialised LDS
-    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
   if (t_start < ntiles) {

@@ -116,6 +116,17 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   // the dO tile has the same lane -> (row, chunk) map; only its row stride may differ (the difference can be
   // negative: it is added in the VGPR offset, whose sum row*do_rs + chunk is not; the scalar offset is unsigned)
   const int do_delta = ((C::BQ / C::NW) * wave + lane / C::CPR) * (do_rs - q_rs);
+#ifndef FA_DMA_LEGACY
+  // dma_pieces (fa_common.h): M0 once per group of up to four 1-KiB pieces; piece j of a group carries the immediate
+  // offset 1024*j, which also moves the global address, so it is taken out of the per-lane source offset here
+  constexpr int DMA_GRP = C::DMA_PER_MAT < 4 ? C::DMA_PER_MAT : 4;
+  int dma_do[C::DMA_PER_MAT];
+#pragma unroll
+  for (int i = 0; i < C::DMA_PER_MAT; ++i) {
+    dma_do[i] = dma_src[i] + do_delta + C::RPI * i * (do_rs - q_rs) - 1024 * (i % DMA_GRP);
+    dma_src[i] -= 1024 * (i % DMA_GRP);
+  }
+#endif
   int row_off[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   // A ragged last query tile leaves its tail rows to an out-of-range DMA; make sure those LDS bytes
   // are finite (they are multiplied by P = 0).
   if (p.Sq % C::BQ != 0) {
-    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
 
@@ -155,12 +166,21 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
       if (t > t_start + 1) return;  // keep real (random) data in both buffers: zeros would raise the clock
 #endif
       const int soff_q = t * C::BQ * q_rs, soff_do = t * C::BQ * do_rs;
+#ifndef FA_DMA_LEGACY
+#pragma unroll
+      for (int g = 0; g < C::DMA_PER_MAT; g += DMA_GRP) {
+        const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * g) * C::ROWB;
+        dma_pieces<DMA_GRP>(rq, lds_addr_of(smem + dst), dma_src + g, soff_q);
+        dma_pieces<DMA_GRP>(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_do + g, soff_do);
+      }
+#else
 #pragma unroll
       for (int i = 0; i < C::DMA_PER_MAT; ++i) {
         const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * i) * C::ROWB;
         dma16(rq, lds_addr_of(smem + dst), dma_src[i], soff_q);
         dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i] + do_delta + C::RPI * i * (do_rs - q_rs), soff_do);
       }
+#endif
       rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4);
     };
     // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet

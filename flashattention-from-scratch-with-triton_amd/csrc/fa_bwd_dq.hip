@@ -43,10 +43,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
   // causal: a workgroup takes the query-tile pair (nq-1-i, i) -> equal work everywhere (see fa_fwd.hip)
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -56,6 +53,9 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   const int idx = w - bh * per_bh;
   const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
+  // lane coordinates are re-derived per pass from an opaque thread id: as pass-invariant values hipcc keeps them (and
+  // the addresses computed from them) live across both passes and spills them at the 168-register budget
+  const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
   const int qt = paired ? (pass == 0 ? p.n_tiles - 1 - idx : idx) : (CAUSAL ? p.n_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 32;
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + RPI * i + lane / C::CPR;
     dma_src[i] = row * kv_rs + swz_chunk<D>(row, lane % C::CPR) * 16;
+#ifndef FA_DMA_LEGACY
+    dma_src[i] -= 1024 * i;  // dma_pieces: the immediate offset of piece i also moves the global address
+#endif
   }
   int row_off[C::KS];  // A-operand row reads (K rows and V rows)
 #pragma unroll
@@ -138,6 +141,12 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
 
   auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
     const int soff = t * C::BN * kv_rs;
+#ifndef FA_DMA_LEGACY
+    const int dst0 = buf * C::TILE_BYTES + 16 * wave * C::ROWB;  // this wave's 16 rows = DMA_PER_MAT consecutive KiB
+    dma_pieces<C::DMA_PER_MAT>(rk, lds_addr_of(smem + dst0), dma_src, soff);
+    dma_pieces<C::DMA_PER_MAT>(rv, lds_addr_of(smem + 2 * C::TILE_BYTES + dst0), dma_src, soff);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < C::DMA_PER_MAT; ++i) {
       const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   };
 
   if (p.Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS
-    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
   dma_tile(0, 0);

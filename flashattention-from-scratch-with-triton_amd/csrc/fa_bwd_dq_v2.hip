@@ -36,10 +36,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
   // causal: each workgroup takes the query-tile pair (nq-1-i, i) -> equal work everywhere (fa_fwd_v2.hip)
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -49,6 +46,8 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
   const int idx = w - bh * per_bh;
   const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
+  // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
+  const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
   const int qt = paired ? (pass == 0 ? p.n_tiles - 1 - idx : idx) : (CAUSAL ? p.n_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 64;
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
   const int nfull = min(n_mine, CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN);
 
   if (p.Sk % C::BN != 0) {  // see fa_fwd_v2.hip: never expose uninitialised LDS behind a ragged last tile
-    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
 

@@ -110,9 +110,34 @@ FA_DEVINL int lds_off(int row, int chunk) {
   return row * (D * 2) + swz_chunk<D>(row, chunk) * 16;
 }
 
+// A value hipcc must treat as freshly computed here: address arithmetic that depends on it can no longer be hoisted
+// to kernel entry and carried (or spilled) across the tile loop.
+FA_DEVINL int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// Lane index 0..63 recomputed from EXEC (needs all lanes active) instead of read from the thread-id VGPR: nothing then
+// has to stay live (or be spilled) across a tile loop just to re-derive lane coordinates for the next pass.
+FA_DEVINL int lane_id_now() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
+
 FA_DEVINL u32x4 lds_read16(const FA_LDS char* p) { return *(const FA_LDS u32x4*)p; }
 FA_DEVINL void lds_write16(FA_LDS char* p, u32x4 v) { *(FA_LDS u32x4*)p = v; }
 FA_DEVINL void lds_write8(FA_LDS char* p, u32x2 v) { *(FA_LDS u32x2*)p = v; }
+
+// Zero the first `bytes` of the workgroup's LDS (ragged last tiles: an out-of-range LDS-DMA may leave its destination
+// untouched, and whatever lies there is multiplied by P = 0).  Thread id and the zero vector are made opaque so that
+// this rarely taken block adds nothing to the register pressure of the kernel around it.
+FA_DEVINL void lds_zero_fill(FA_LDS char* smem, int bytes, int nthreads, int tid) {
+  const int t = opaque(tid);
+  u32x4 z = {0u, 0u, 0u, 0u};
+  asm volatile("" : "+v"(z));
+  for (int i = t * 16; i < bytes; i += nthreads * 16) lds_write16(smem + i, z);
+}
 
 // ds_read_b64_tr_b16: needs EXEC all ones and an 8-byte aligned address per lane.
 FA_DEVINL i16x4 lds_read_tr(const FA_LDS char* p) {
@@ -175,6 +200,30 @@ FA_DEVINL void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, int voff, i
       : "=&s"(keep)
       : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
 }
+// N consecutive 1-KiB pieces (N = 1, 2 or 4) of ONE matrix with M0 written once: piece i lands at lds_addr + 1024*i.
+// The instruction's immediate offset moves the LDS destination AND the global address, so `voff[i]` must already be
+// the piece's source offset MINUS 1024*i (callers precompute it; it stays >= 0 because piece i starts at tile row
+// i * (1024 / row bytes) and rows are at least that long).  M0 is not restored: hipcc reserves it and never touches it in
+// these kernels (no compiler-generated m0 use in the .s), which saves two scalar moves per piece on the scalar pipe
+// that every wave of the SIMD shares.
+template <int N>
+FA_DEVINL void dma_pieces(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, const int* voff, int soff) {
+  static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 pieces per M0 setting (12-bit immediate offset)");
+  if constexpr (N == 1) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff[0]), "s"(rsrc), "s"(soff));
+  } else if constexpr (N == 2) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen offset:1024 lds"
+                 :: "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff));
+  } else {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+                 "buffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds"
+                 :: "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsrc), "s"(soff));
+  }
+}
 FA_DEVINL unsigned lds_addr_of(const FA_LDS char* p) { return (unsigned)(uintptr_t)p; }
 
 // ---- cross-half exchange (lanes l <-> l + 32) -----------------------------
@@ -214,6 +263,11 @@ FA_DEVINL int xcd_remap(int b, int n) {
 template <int D, typename T>
 FA_DEVINL void store_tile_rows(const f32x16 (&acc)[D / 32], float mul, FA_LDS char* stage,
                                __amdgpu_buffer_rsrc_t dst, int row0_bytes, int lane) {
+  // Opaque lane id: everything below is address arithmetic on `lane` that does not change from pass to pass, so hipcc
+  // hoists it to kernel entry, keeps ~20 values live across the whole tile loop and, at the 168-register budget of
+  // three workgroups per CU, spills them (22 dwords of scratch per lane in the headline dQ kernel).  Recomputing
+  // them here costs ~30 VALU ops per pass.
+  asm volatile("" : "+v"(lane));
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int db = 0; db < D / 32; ++db) {

@@ -25,6 +25,17 @@
 
 namespace fa {
 
+// A/B hooks (tools/build_variant.sh): FA_FWD_PRIO 1 = raise the wave's priority over its MFMA chains, 2 = over its
+// softmax (VALU) phase; FA_FWD_OCC = workgroups per CU the D = 64 register allocation is held to.
+#ifndef FA_FWD_PRIO
+#define FA_FWD_PRIO 1
+#endif
+#ifndef FA_FWD_OCC
+#define FA_FWD_OCC 3
+#endif
+#define FA_PRIO_MFMA(on) do { if (FA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(on); } while (0)
+#define FA_PRIO_VALU(on) do { if (FA_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(on); } while (0)
+
 template <int D>
 struct FwdCfg {
   static constexpr int BM = 128;           // query rows per workgroup
@@ -45,16 +56,13 @@ constexpr float kDeferLog2 = 6.0f;
 constexpr float kLazySumMax = 8192.0f;
 
 template <int D, typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel(FwdParams p) {
   using C = FwdCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
   // ---- which (batch*head, q tile) ----
   // Work list: non-causal -> one 128-row query tile per workgroup.  Causal -> query tile i streams i+1
@@ -67,6 +75,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   const int idx = w - bh * per_bh;
   const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
+  // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
+  const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
   const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 32;
@@ -108,6 +118,9 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + RPI * i + lane / C::CPR;
     dma_src[i] = row * kv_rs + swz_chunk<D>(row, lane % C::CPR) * 16;
+#ifndef FA_DMA_LEGACY
+    dma_src[i] -= 1024 * i;  // dma_pieces: the immediate offset of piece i also moves the global address
+#endif
   }
   // ---- fragment read addresses (loop invariant) ----
   int k_off[C::KS];
@@ -142,6 +155,12 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
 
   auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
     const int soff = t * C::BN * kv_rs;
+#ifndef FA_DMA_LEGACY
+    const int dst0 = buf * C::TILE_BYTES + 16 * wave * C::ROWB;  // this wave's 16 rows = DMA_PER_MAT consecutive KiB
+    dma_pieces<C::DMA_PER_MAT>(rk, lds_addr_of(smem + dst0), dma_src, soff);
+    dma_pieces<C::DMA_PER_MAT>(rv, lds_addr_of(smem + 2 * C::TILE_BYTES + dst0), dma_src, soff);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < C::DMA_PER_MAT; ++i) {
       const int dst = buf * C::TILE_BYTES + (16 * wave + RPI * i) * C::ROWB;
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
       if (!use[0] && !use[1]) return true;  // nothing of this tile is visible to the wave
     }
     f32x16 sacc[2];
+    FA_PRIO_MFMA(1);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       if (MASKED && !use[b]) continue;
@@ -295,6 +315,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
         sacc[b] = T::mfma(a, qf[ks], sacc[b]);
       }
     }
+    FA_PRIO_MFMA(0);
+    FA_PRIO_VALU(1);
     const float mc = m * c2;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -314,8 +336,13 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
       }
     }
     const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
-    if (__builtin_amdgcn_ballot_w64(!(lsum <= kLazySumMax)) != 0) return false;
+    if (__builtin_amdgcn_ballot_w64(!(lsum <= kLazySumMax)) != 0) {
+      FA_PRIO_VALU(0);
+      return false;
+    }
     l += lsum;
+    FA_PRIO_VALU(0);
+    FA_PRIO_MFMA(1);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       if (MASKED && !use[b]) continue;
@@ -330,6 +357,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
         oacc[db] = T::mfma(a1, pf1, oacc[db]);
       }
     }
+    FA_PRIO_MFMA(0);
     return true;
   };
 
@@ -337,7 +365,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void fa_fwd_kernel(FwdParam
 
   // ---- main loop: one barrier per tile; every wave runs exactly ntiles iterations ----
   if (p.Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS (out-of-range DMA may not write)
-    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
   dma_tile(0, 0);

@@ -60,10 +60,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
   // Work list: non-causal -> one 256-row query tile per workgroup.  Causal -> query tile i costs i+1
   // K/V steps, so each workgroup takes the PAIR (nq-1-i, i): every workgroup then streams nq+1 steps
@@ -75,6 +72,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   const int idx = w - bh * per_bh;
   const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
+  // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
+  const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
   const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 64;
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   // not expose uninitialised LDS (0 * NaN in P V), so clear the ring once.  Later rounds only ever
   // leave finite stale K/V there.
   if (p.Sk % C::BN != 0) {
-    for (int i = tid * 16; i < C::LDS_BYTES; i += C::NT * 16) lds_write16(smem + i, u32x4{0, 0, 0, 0});
+    lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
 
