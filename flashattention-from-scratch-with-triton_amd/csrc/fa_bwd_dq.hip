@@ -254,8 +254,10 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 }
 
 hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v2.hip
+hipError_t launch_bwd_dq_v3(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v3.hip
 
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  if (D == 64 && pick_dq3(g_force_dq, p.Sk)) return launch_bwd_dq_v3(p, dtype, causal, s);
   // family 2 reads contiguous operands only; strided views always take family 1
   if (p.all_contiguous(D) && pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
     return launch_bwd_dq_v2(p, dtype, causal, s);

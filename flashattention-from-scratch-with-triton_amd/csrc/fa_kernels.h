@@ -72,6 +72,11 @@ inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal
   const long wgs2 = (long)B * H * (causal ? (tiles256 + 1) / 2 : tiles256);
   return (!causal && wgs2 >= 512) ? 2 : 1;
 }
+// dQ family 3 (fa_bwd_dq_v3.hip, D = 64): the per-wave three-stage pipeline.
+inline bool pick_dq3(int forced, int Sk) {
+  if (forced) return forced == 3;
+  return false;
+}
 inline int pick_dkv_impl(int forced, int D, int Sq) {
   if (D != 64 && D != 128) return 1;
   if (forced) return forced;

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Bitwise comparison of two schedule families of one kernel (same maths, same rounding points, same accumulation
+order => identical bits) over a list of shapes, through the C ABI.  usage: check_family.py {fwd|dq|dkv} A B"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flashattention-from-scratch-with-triton_amd"))
+import torch  # noqa: E402
+
+import _mi355fa as host  # noqa: E402
+
+kern, fa_, fb_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+lib = host.lib
+lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+SHAPES = [(1, 2, 64, 64), (1, 2, 128, 128), (2, 3, 192, 192), (1, 2, 256, 256), (2, 2, 320, 320), (1, 2, 448, 448),
+          (1, 1, 512, 512), (2, 2, 1024, 1024), (1, 2, 500, 500), (1, 2, 77, 333), (1, 2, 333, 77), (1, 1, 129, 65),
+          (1, 2, 128, 320), (1, 2, 256, 1024), (1, 1, 1, 700), (4, 32, 4096, 4096), (1, 4, 8192, 8192)]
+P = lambda t: t.data_ptr()
+bad = 0
+for dt, code in ((torch.bfloat16, 1), (torch.float16, 0)):
+    for causal in (0, 1):
+        for (B, H, Sq, Sk) in SHAPES:
+            D = 64
+            torch.manual_seed(Sq * 7 + Sk)
+            Q, dO = (torch.randn(B, H, Sq, D, device="cuda", dtype=dt) for _ in range(2))
+            K, V = (torch.randn(B, H, Sk, D, device="cuda", dtype=dt) for _ in range(2))
+            O = torch.empty_like(Q)
+            LSE = torch.empty(B, H, Sq, device="cuda", dtype=torch.float32)
+            st = torch.cuda.current_stream().cuda_stream
+            sc = D ** -0.5
+            outs = []
+            for fam in (fa_, fb_):
+                f = [0, 0, 0]
+                f[{"fwd": 0, "dq": 1, "dkv": 2}[kern]] = fam
+                lib.fa_debug_force_impl(*f)
+                o, lse = torch.full_like(Q, float("nan")), torch.full_like(LSE, float("nan"))
+                assert lib.fa_fwd(P(Q), P(K), P(V), P(o), P(lse), B, H, Sq, Sk, D, code, causal, sc, st) == 0
+                if kern == "fwd":
+                    outs.append((o, lse))
+                    continue
+                dq, delta = torch.full_like(Q, float("nan")), torch.full_like(LSE, float("nan"))
+                assert lib.fa_bwd_dq(P(Q), P(K), P(V), P(o), P(dO), P(lse), P(dq), P(delta), B, H, Sq, Sk, D, code, causal, sc, st) == 0, lib.fa_last_error()
+                if kern == "dq":
+                    outs.append((dq, delta))
+                    continue
+                dk, dv = torch.full_like(K, float("nan")), torch.full_like(V, float("nan"))
+                assert lib.fa_bwd_dkv(P(Q), P(K), P(V), P(dO), P(lse), P(delta), P(dk), P(dv), B, H, Sq, Sk, D, code, causal, sc, st) == 0
+                outs.append((dk, dv))
+            torch.cuda.synchronize()
+            lib.fa_debug_force_impl(0, 0, 0)
+            same = all(torch.equal(a.view(torch.int16 if a.dtype != torch.float32 else torch.int32),
+                                   b.view(torch.int16 if b.dtype != torch.float32 else torch.int32))
+                       for a, b in zip(outs[0], outs[1]))
+            nan = any(torch.isnan(x.float()).any().item() for x in outs[1])
+            if not same or nan:
+                bad += 1
+                d = [(a.float() - b.float()).abs().max().item() for a, b in zip(outs[0], outs[1])]
+                print("MISMATCH %s causal=%d B%d H%d Sq%d Sk%d  max|diff| %s nan=%s" % (dt, causal, B, H, Sq, Sk, d, nan), flush=True)
+print("check_family %s %d vs %d: %s" % (kern, fa_, fb_, "ALL BIT-IDENTICAL" if not bad else "%d mismatches" % bad))
+sys.exit(1 if bad else 0)
