@@ -56,8 +56,9 @@ def _in_place(*tensors):
     """The reference makes every input contiguous (M:138-140,156): a 64 MiB copy per tensor at the headline size
     whenever Q/K/V are transposed views of a fused projection ([B,S,H,D] seen as [B,H,S,D]).  The kernels read such
     views in place (fa_*_strided); only layouts they cannot address (non-unit head-dim stride, rows not 16-byte
-    multiples, K and V with different sequence strides) are still copied."""
-    return tuple(t if _fa.strided_ok(t) else t.contiguous() for t in tensors)
+    multiples, a base pointer off a 16-byte boundary, K and V with different sequence strides) are still copied --
+    into a fresh (hence aligned) allocation."""
+    return tuple(t if _fa.strided_ok(t) else t.clone(memory_format=torch.contiguous_format) for t in tensors)
 
 
 def _kv_in_place(K, V):
@@ -67,9 +68,22 @@ def _kv_in_place(K, V):
     return K, V
 
 
+def _check_qkv(Q, K, V):
+    """The kernels take B and H from Q and address K / V slices as b*stride_b + h*stride_h: a K or V with fewer batches
+    or heads would be read past its allocation (the reference's descriptors cover the whole tensor instead).  MQA / GQA
+    callers pass K / V expanded to Q's head count (a stride-0 view is read in place)."""
+    assert Q.ndim == 4 and K.ndim == 4 and V.ndim == 4
+    assert K.shape[:2] == Q.shape[:2], "K must have Q's batch and head counts (expand shared K/V heads)"
+    assert V.shape == K.shape, "K and V must have the same shape"
+    assert Q.shape[-1] == K.shape[-1], "Q, K, V must share the head dim"
+    assert Q.device == K.device == V.device, "Q, K, V must be on the same device"
+    assert Q.dtype == K.dtype == V.dtype
+
+
 def flash_attention_forward(Q, K, V, is_causal):
     """Allocate O / LSE and enqueue the forward kernel (M:14-60).  Q, K, V: contiguous, or strided views accepted
     by _mi355fa.strided_ok with K and V sharing their sequence stride."""
+    _check_qkv(Q, K, V)
     B, H, S_q, D = Q.shape
     _, _, S_k, _ = K.shape
     O = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
@@ -85,15 +99,20 @@ def flash_attention_forward(Q, K, V, is_causal):
 
 def flash_attention_backward(Q, K, V, O, dO, LSE, is_causal):
     """Allocate dQ/dK/dV/delta and enqueue dQ (+delta) then dK/dV (M:62-128)."""
+    _check_qkv(Q, K, V)
+    assert O.shape == Q.shape and dO.shape == Q.shape and LSE.shape == Q.shape[:3]
+    assert O.device == dO.device == LSE.device == Q.device
     B, H, S_q, D = Q.shape
     _, _, S_k, _ = K.shape
-    dQ = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
-    dK = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
-    dV = torch.empty((B, H, S_k, D), dtype=Q.dtype, device=Q.device)
+    if S_q == S_k:   # self-attention: one allocation for the three gradients (M:71-73 makes three)
+        dQ, dK, dV = torch.empty((3, B, H, S_q, D), dtype=Q.dtype, device=Q.device).unbind(0)
+    else:
+        dQ = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
+        dK, dV = torch.empty((2, B, H, S_k, D), dtype=Q.dtype, device=Q.device).unbind(0)
     delta = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
     dt, causal, scale = _DTYPES[Q.dtype], 1 if is_causal else 0, 1 / (D ** 0.5)
-    if not O.is_contiguous():   # normally the tensor flash_attention_forward returned
-        O = O.contiguous()
+    if not O.is_contiguous() or O.data_ptr() & 15:   # normally the tensor flash_attention_forward returned
+        O = O.clone(memory_format=torch.contiguous_format)
     sq, sk, sv, sdo = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V), _fa.strides3(dO)
     with _OnDevice(Q.device):
         s = _stream(Q.device.index)
@@ -120,7 +139,9 @@ class FlashAttentionFunction(torch.autograd.Function):
         assert Q.shape[-1] == K.shape[-1] == V.shape[-1]
         assert Q.ndim == 4 and K.ndim == 4 and V.ndim == 4
         assert Q.shape[-1] in (64, 128), "head dim must be 64 or 128"
-        if Q.is_contiguous() and K.is_contiguous() and V.is_contiguous():
+        _check_qkv(Q, K, V)   # beyond M:133-136: the raw-pointer kernels cannot bound a smaller K / V themselves
+        if Q.is_contiguous() and K.is_contiguous() and V.is_contiguous() and not (
+                (Q.data_ptr() | K.data_ptr() | V.data_ptr()) & 15):
             Q_, K_, V_ = Q, K, V
         else:                         # no copy for views the kernels can read in place (M:138-140 copies them)
             (Q_,) = _in_place(Q)
@@ -133,7 +154,7 @@ class FlashAttentionFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dO):
         Q, K, V, O, LSE = ctx.saved_tensors
-        dO_ = dO if dO.is_contiguous() else _in_place(dO)[0]
+        dO_ = dO if (dO.is_contiguous() and not dO.data_ptr() & 15) else _in_place(dO)[0]
         dQ, dK, dV = flash_attention_backward(Q, K, V, O, dO_, LSE, ctx.is_causal)
         return dQ, dK, dV, None
 

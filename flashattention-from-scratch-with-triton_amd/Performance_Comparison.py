@@ -6,11 +6,44 @@ naive_attention (P:130-144); providers 'naive' / 'triton' / 'pytorch' keep their
 = this repository's HIP kernels behind flash_attention, so the reference's driver loop runs
 unchanged); modes fwd / fwd_bwd / bwd := fwd_bwd - fwd (P:92-93); counted FLOPs P:101-107.
 Added: a `dtype` argument (the reference is fp16-only; the MI355X headline is bf16).
+The 'pytorch' provider pins the FLASH backend under 16-bit autocast exactly as P:53-57 does; where this PyTorch-ROCm
+build refuses that backend for the shape / dtype, it falls back to the default backend selection and says so:
+`last_sdpa_backend()` returns "flash" or "default (<why flash was refused>)" for the most recent 'pytorch' run.
 """
 from typing import Literal, Tuple
 
 import torch
 import torch.nn.functional as F
+from torch.amp import autocast
+from torch.nn.attention import SDPBackend, sdpa_kernel
+
+_sdpa_backend = {"last": None}
+
+
+def last_sdpa_backend():
+    """Which SDPA backend the most recent provider='pytorch' benchmark ran: "flash" (pinned, as in the reference) or
+    "default (...)" when the pin was refused by this build."""
+    return _sdpa_backend["last"]
+
+
+def _sdpa_flash(Q, K, V, is_causal, dtype):
+    with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+        with autocast(device_type=Q.device.type, dtype=dtype):
+            return F.scaled_dot_product_attention(Q, K, V, is_causal=is_causal)
+
+
+def _pick_sdpa(Q, K, V, is_causal, dtype):
+    """P:53-57 pins SDPBackend.FLASH_ATTENTION + autocast; try that once (forward AND backward), otherwise default."""
+    try:
+        O = _sdpa_flash(Q, K, V, is_causal, dtype)
+        if O.requires_grad:
+            O.sum().backward()
+            Q.grad = K.grad = V.grad = None
+        _sdpa_backend["last"] = "flash"
+        return lambda: _sdpa_flash(Q, K, V, is_causal, dtype)
+    except RuntimeError as e:
+        _sdpa_backend["last"] = "default (%s)" % str(e).strip().split("\n")[0][:120]
+        return lambda: F.scaled_dot_product_attention(Q, K, V, is_causal=is_causal)
 
 
 def benchmark_attention(
@@ -41,8 +74,7 @@ def benchmark_attention(
         def fn():
             return flash_attention(Q, K, V, is_causal)
     else:  # pytorch
-        def fn():
-            return F.scaled_dot_product_attention(Q, K, V, is_causal=is_causal)
+        fn = _pick_sdpa(Q, K, V, is_causal, dtype)
 
     Q.grad = None
     K.grad = None

@@ -62,15 +62,20 @@ def strides3(t):
 
 
 def strided_ok(t):
-    """True if the kernels can read `t` in place: unit head-dim stride, the other strides multiples of 8 elements
-    (16-byte rows; batch / head may be 0), rows not overlapping, 16-byte aligned base (include/mi355fa.h)."""
+    """True if the kernels can read `t` in place: 16-byte aligned base, and either contiguous or unit head-dim stride
+    with the other strides multiples of 8 elements (16-byte rows; batch / head may be 0), rows not overlapping and one
+    (batch, head) slice within 2^31 bytes (include/mi355fa.h).  Anything else is copied by the caller."""
+    if t.data_ptr() % 16:
+        return False
     if t.is_contiguous():
         return True
-    if t.stride(3) != 1 or t.data_ptr() % 16:
+    if t.stride(3) != 1:
         return False
     if t.stride(2) < t.shape[3]:
         return False
     if t.shape[2] > 1 and t.stride(2) % 8:
+        return False
+    if (t.shape[2] - 1) * t.stride(2) * 2 + 2 * t.shape[3] > (1 << 31) - 1:   # 32-bit buffer offsets inside a slice
         return False
     # batch / head strides may be 0: an expanded K/V shared by several heads is read in place
     return all(t.shape[i] == 1 or (t.stride(i) >= 0 and t.stride(i) % 8 == 0) for i in range(2))

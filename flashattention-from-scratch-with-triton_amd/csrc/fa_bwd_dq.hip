@@ -245,9 +245,13 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
     if (grid >= 3 * 256) return launch<D, T, CAUSAL, 3>(p, s);
   }
   auto kern = fa_bwd_dq_kernel<D, T, CAUSAL, OCC>;
-  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950)
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) return e;
+  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
+    static bool opted_in = false;    // (per template instance; a racing second call only repeats an idempotent setting)
+    if (!opted_in) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      opted_in = true;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();

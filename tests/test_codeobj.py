@@ -1,0 +1,50 @@
+"""CPU test: register spills in the gfx950 kernels of libmi355fa.so.
+
+The code objects are read straight out of the shared library (tools/codeobj.py: ELF section .hip_fatbin -> clang
+offload bundles -> AMDGPU metadata notes); no GPU and no HIP runtime are involved.  A kernel the schedule rule of
+csrc/fa_kernels.h can select must not spill: scratch traffic showed up as 1.43x the algorithmic HBM bytes in round 1's
+headline dQ kernel.  Variants that only fa_debug_force_impl() can reach are listed explicitly.
+"""
+import os
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import codeobj  # noqa: E402
+
+# forced-only variants (never picked by pick_fwd_dq_impl / pick_dq3 / pick_dkv_impl): causal launches never take the
+# 64-rows-per-wave family 2 forward / dQ
+FORCED_ONLY = ("fa_bwd_dq2_kernelINS_4BF16ELb1E", "fa_bwd_dq2_kernelINS_4FP16ELb1E",
+               "fa_fwd2_kernelINS_4BF16ELb1E", "fa_fwd2_kernelINS_4FP16ELb1E")
+
+
+def test_library_contains_the_expected_kernels():
+    ks = codeobj.kernels()
+    names = " ".join(k["name"] for k in ks)
+    for stem in ("fa_fwd_kernel", "fa_fwd2_kernel", "fa_bwd_dq_kernel", "fa_bwd_dq2_kernel", "fa_bwd_dq3_kernel",
+                 "fa_bwd_dkv_kernel", "fa_bwd_dkv2_kernel"):
+        assert stem in names, stem
+    assert len(ks) >= 40
+    assert all(k["wg"] == 256 for k in ks)
+
+
+def test_rule_selectable_kernels_do_not_spill():
+    bad = [(codeobj.demangle_short(k["name"]), k["spill"], k["scratch"]) for k in codeobj.kernels()
+           if (k["spill"] or k["scratch"]) and not any(f in k["name"] for f in FORCED_ONLY)]
+    # (SGPR spills go to VGPR lanes with v_writelane, not to memory: they cost no scratch traffic and are not counted)
+    assert not bad, "kernels with register spills / scratch: %s" % bad
+
+
+def test_register_budgets_match_the_intended_occupancy():
+    """VGPR + AGPR per lane against the workgroups-per-CU each kernel is designed for (512 registers per SIMD lane,
+    allocation granule 8): 3 workgroups per CU need <= 168, 2 need <= 256, 1 needs <= 512."""
+    for k in codeobj.kernels():
+        n = k["name"]
+        total = k["vgpr"]      # .vgpr_count already includes the AGPRs on gfx950
+        if "fa_fwd_kernelILi64E" in n or "fa_bwd_dq_kernelILi64ENS_4BF16ELb1ELi3E" in n or "fa_bwd_dq_kernelILi64ENS_4BF16ELb0ELi3E" in n:
+            assert total <= 168, (n, total)
+        elif "dkv_kernelILi128E" in n or "dkv2_kernelILi128E" in n:
+            assert total <= 512, (n, total)
+        else:
+            assert total <= 256, (n, total)

@@ -85,3 +85,52 @@ def test_two_rank_gloo_harness_matches_single_process():
     assert abs(ret[0][2] - ref) < 1e-6 * abs(ref) and ret[0][2] == ret[1][2]
     assert ret[0][3] == ret[1][3] == 2.0          # MAX over ranks
     assert ret[0][4] == ret[1][4]                 # both ranks report the same (max) time
+
+
+# ---- bench.py's own rank management: harness only, gloo, no GPU, no kernels ----
+def _bench(args, env=None, timeout=150):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr
+
+
+@pytest.mark.timeout(300)
+def test_bench_spawns_its_own_ranks_and_shards_config5():
+    rc1, one, err1 = _bench(["--gpus", "1", "--harness-selftest", "--config", "5", "--steps", "3", "--warmup", "1"])
+    rc2, two, err2 = _bench(["--gpus", "2", "--harness-selftest", "--config", "5", "--steps", "3", "--warmup", "1"])
+    assert rc1 == 0 and rc2 == 0, (err1, err2)
+    assert len(one) == 1 and len(two) == 1            # exactly ONE JSON line, printed by rank 0
+    a, b = one[0], two[0]
+    assert (a["n_gpus"], b["n_gpus"]) == (1, 2) and a["scaling"] == b["scaling"] == "strong"
+    assert a["global_batch"] == b["global_batch"] == 64      # the shards cover the global batch of BASELINE configs[4]
+    assert abs(a["checksum"] - b["checksum"]) <= 1e-9 * abs(a["checksum"])   # same whole-job data at N = 1 and N = 2
+    assert b["steps"] == 3 and b["warmup"] == 1 and b["ms_per_step"] > 0
+
+
+@pytest.mark.timeout(120)
+def test_bench_rank_count_mismatch_is_an_error_not_a_single_process_run():
+    rc, lines, err = _bench(["--gpus", "2", "--harness-selftest"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and not lines and "WORLD_SIZE=1" in err
+    # without a GPU the real benchmark refuses to start ranks at all (and never falls back to anything)
+    if not torch.cuda.is_available():
+        rc, lines, err = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert rc != 0 and not lines and "GPU" in err
+
+
+def test_bench_metric_string_follows_the_arguments():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.CONFIGS["5"] == (64, 32, 8192, 64, "strong") and bench.CONFIGS["3"][:4] == (4, 32, 4096, 64)
+    a = bench.parse_args([])
+    assert (a.gpus, a.config) == (1, "3") and a.steps * 1.3 < 60          # the default finishes within minutes
+    assert bench.flops_fwd(64, 32, 8192, 8192, 64, True) * 3.5 == 61572651155456     # tests/golden/kat.json
+    assert len(bench.kernel_source_hash()) == 16

@@ -29,9 +29,8 @@ def _cases(n=int(os.environ.get("FA_FUZZ_CASES", "28")), seed=int(os.environ.get
         D = rng.choice([64, 64, 64, 128])
         causal = rng.random() < 0.5
         Sq = rng.choice(edges)
-        Sk = Sq if rng.random() < 0.5 else rng.choice(edges)
-        if causal and Sk > Sq:       # the reference's causal mask is top-left aligned (K:102): keys beyond Sq are dead
-            Sk = Sq                  # weight -- keep the causal cases square or Sq > Sk
+        Sk = Sq if rng.random() < 0.5 else rng.choice(edges)   # causal with Sk > Sq included: the reference's mask is
+        # top-left aligned (K:102), so keys beyond Sq are invisible -- their dK / dV must still be written, as zeros
         B, H = rng.choice([(1, 1), (1, 2), (2, 3), (1, 5)])
         out.append((B, H, Sq, Sk, D, causal, F16 if i % 2 else BF16))
     return out
@@ -57,6 +56,8 @@ def test_random_shape_against_fp64_and_itself(case):
     # the same inputs: at degenerate sizes (two rows, gradients that are pure cancellation) even those sit at 2e-2
     peer = fo.fwd_bwd_tiled(Q, K, V, dO, causal) if dtype == F16 else dict(
         zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))
+    if causal and Sk > Sq:
+        assert (r["dK"][:, :, Sq:] == 0).all() and (r["dV"][:, :, Sq:] == 0).all()
     for k in ("O", "dQ", "dK", "dV"):
         assert torch.equal(r[k], r2[k]), (k, "not deterministic")
         out = r[k].cpu()

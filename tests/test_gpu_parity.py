@@ -24,9 +24,10 @@ def _host():
     return M
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["auto", "family1", "family2"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "family1", "family2", "family3"])
 def impl(request):
-    """Run a test under the automatic schedule rule and with each D=64 schedule family forced."""
+    """Run a test under the automatic schedule rule and with each D=64 schedule family forced (family 3 exists for
+    the dQ kernel only: forward and dK/dV then run family 1)."""
     import ctypes
     import _mi355fa as fa
     fn = fa.lib.fa_debug_force_impl
@@ -104,6 +105,13 @@ SHAPES = [
     (1, 1, 256, 256, 128, True),     # D = 128 (fixture iv shape)
     (1, 2, 500, 500, 128, True),
     (1, 2, 333, 600, 128, False),
+    # causal with S_k > S_q: top-left aligned mask, keys >= S_q are invisible to every query -- their dK / dV
+    # rows must come out exactly 0 (zero-tile workgroups, paired passes mixing empty and non-empty key tiles)
+    (1, 2, 128, 320, 64, True),
+    (1, 1, 77, 333, 64, True),
+    (2, 3, 256, 1024, 64, True),
+    (1, 2, 128, 320, 128, True),
+    (1, 1, 77, 333, 128, True),
 ]
 
 
@@ -123,6 +131,8 @@ def test_against_fp64_oracle(shape, dtype, impl):
     assert fo.rel_fro(gt["LSE"], r["LSE"]) < 1e-3
     # delta is computed from the ROUNDED O as in the reference (K:210-211): its error is |dO| * ulp(O) * sqrt(D)
     assert (r["delta"].double() - gt["delta"]).abs().max() < (1e-1 if dtype == BF16 else 1.5e-2)
+    if causal and Sk > Sq:                  # keys no query can see: every element of their gradient rows is written, as 0
+        assert (r["dK"][:, :, Sq:] == 0).all() and (r["dV"][:, :, Sq:] == 0).all()
     names = ["O", "dQ", "dK", "dV"]
     for k in list(names):
         if gt[k].abs().max() < 1e-9:        # a single visible key: softmax is constant, dQ = dK = 0 exactly
@@ -156,22 +166,53 @@ def test_autograd_path_and_strided_inputs():
     assert o.dtype == F16 and q.grad.shape == q.shape
 
 
-def test_rescale_branch_is_exercised_by_a_late_spike(impl):
+@pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
+def test_rescale_branch_is_exercised_by_a_late_spike(impl, dtype):
     """Online-softmax max must jump in a LATE tile: one key far down the sequence dominates one query
-    (cdna guide rule 26: bounded random data rarely takes the rescale branch late)."""
+    (cdna guide rule 26: bounded random data rarely takes the rescale branch late).  bf16: its forward
+    score chain starts from the -m block, dQ / dK/dV fold the scale into Q / K (one more 2^-9 rounding of the exponent
+    argument) -- the same spikes must hold there at the bf16 tolerances of test_against_fp64_oracle."""
     B, H, S, D = 1, 1, 640, 64
-    Q, K, V, dO = rand_inputs(B, H, S, S, D, F16, seed=9)
-    K[0, 0, 517] = (Q[0, 0, 600].float() * 0.9).half()     # huge score for row 600 at key 517 (tile 8)
-    K[0, 0, 70] = (Q[0, 0, 100].float() * 0.7).half()
+    Q, K, V, dO = rand_inputs(B, H, S, S, D, dtype, seed=9)
+    K[0, 0, 517] = (Q[0, 0, 600].float() * 0.9).to(dtype)     # huge score for row 600 at key 517 (tile 8)
+    K[0, 0, 70] = (Q[0, 0, 100].float() * 0.7).to(dtype)
     # a jump of > 2^13 in one step: forces the lazy-max forward tile to bail out to the exact path late
     # (raw score 1.7 * |q|^2 ~ 110 -> exp2(110 * 0.18) ~ 2^20 against the stale max)
-    K[0, 0, 450] = (Q[0, 0, 520].float() * 1.7).half()
+    K[0, 0, 450] = (Q[0, 0, 520].float() * 1.7).to(dtype)
     for causal in (False, True):
         gt = fo.attention_fp64(Q, K, V, dO, causal)
         r = run_gpu_raw(Q, K, V, dO, causal)
-        for k in ("O", "dQ", "dK", "dV"):
-            assert fo.rel_fro(gt[k], r[k]) < 1e-3, (k, causal)
-        assert (r["LSE"].double() - gt["LSE"]).abs().max() < 1e-3
+        if dtype == F16:
+            for k in ("O", "dQ", "dK", "dV"):
+                assert fo.rel_fro(gt[k], r[k]) < 1e-3, (k, causal)
+            assert (r["LSE"].double() - gt["LSE"]).abs().max() < 1e-3
+        else:
+            peer = dict(zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))
+            for k in ("O", "dQ", "dK", "dV"):
+                ours, theirs = fo.rel_fro(gt[k], r[k]), fo.rel_fro(gt[k], peer[k])
+                assert ours < max(2 * theirs, 4e-3), (k, causal, ours, theirs)
+            # the spiked rows have |score * log2e| ~ 20: 2^-9 relative on that is ~4e-2 absolute
+            assert fo.rel_fro(gt["LSE"], r["LSE"]) < 2e-3
+
+
+@pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
+def test_large_magnitude_scores_bf16(impl, causal):
+    """Scaled-up Q and K (|s * log2e / sqrt(D)| up to ~50-100): the folded-scale bf16 kernels carry the exponent
+    argument through one extra 8-bit rounding, which randn inputs (|arg| < 10) never stress.  Softmax is nearly one-hot
+    here; the bar is the fp64 oracle at 2x PyTorch's own bf16 SDPA, as everywhere else."""
+    B, H, S, D = 1, 2, 384, 64
+    Q, K, V, dO = rand_inputs(B, H, S, S, D, BF16, seed=21)
+    Q, K = (Q.float() * 2.5).to(BF16), (K.float() * 2.5).to(BF16)
+    arg = (Q.float() @ K.float().transpose(-1, -2)).abs().max().item() * 1.4427 / 8
+    assert 40 < arg < 160, arg
+    gt = fo.attention_fp64(Q, K, V, dO, causal)
+    r = run_gpu_raw(Q, K, V, dO, causal)
+    peer = dict(zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))
+    for k in ("O", "dQ", "dK", "dV"):
+        ours, theirs = fo.rel_fro(gt[k], r[k]), fo.rel_fro(gt[k], peer[k])
+        assert torch.isfinite(r[k].float()).all(), k
+        assert ours < max(2 * theirs, 6e-3), (k, ours, theirs)
+    assert fo.rel_fro(gt["LSE"], r["LSE"]) < 2e-3
 
 
 # ---------------------------------------------------------------- (3) torch SDPA on the device
@@ -416,3 +457,42 @@ def test_expanded_kv_heads_are_read_in_place(dtype):
     for g1, g2 in ((k1.grad, k2.grad), (v1.grad, v2.grad)):
         ref = g2.float().sum(dim=1, keepdim=True)
         assert (g1.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+# ---------------------------------------------------------------- benchmark counterpart (a11 / a12, P:9-144)
+@pytest.mark.parametrize("provider", ["triton", "pytorch", "naive"])
+@pytest.mark.parametrize("mode", ["fwd", "fwd_bwd", "bwd"])
+def test_benchmark_attention_counterpart(provider, mode):
+    """benchmark_attention for every provider x mode on a small shape: returns (ms, tflops) with
+    tflops * ms == counted FLOPs (P:101-107; the FLOP KATs of tests/golden/kat.json), timing() really runs
+    warmup + repeat calls, and the 'pytorch' provider records which SDPA backend ran (P:53-57 pins FLASH)."""
+    from _util import load_kat
+    import Performance_Comparison as P
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c = load_kat()["flops"][3]                        # B2 H4 S256 D64 non-causal (BASELINE configs[0])
+    ms, tf = P.benchmark_attention(provider, mode, c["B"], c["H"], c["S"], c["S"], c["D"], c["causal"], dev,
+                                   warmup=2, repeat=5)
+    assert ms > 0 and tf > 0
+    assert abs(tf * 1e12 * ms * 1e-3 - c[mode]) <= 1e-6 * c[mode]
+    ms_c, tf_c = P.benchmark_attention(provider, "fwd", 1, 2, 256, 256, 64, True, dev, warmup=1, repeat=2)
+    assert abs(tf_c * 1e12 * ms_c * 1e-3 - 4 * 1 * 2 * 256 * 256 * 64 // 2) <= 1e-6 * 4 * 2 * 256 * 256 * 64
+    if provider == "pytorch":
+        b = P.last_sdpa_backend()
+        assert b == "flash" or b.startswith("default ("), b
+    calls = []
+    P.timing(lambda: calls.append(1), 3, 4)
+    assert len(calls) == 7
+
+
+def test_benchmark_bf16_and_naive_matches_kernels():
+    """dtype=bf16 (added argument) runs, and the package's naive_attention agrees with the kernels on device."""
+    import Performance_Comparison as P
+    M = _host()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ms, tf = P.benchmark_attention("triton", "fwd_bwd", 1, 2, 512, 512, 64, True, dev, warmup=1, repeat=2, dtype=BF16)
+    assert ms > 0 and tf > 0
+    Q, K, V, _ = (x.cuda() for x in rand_inputs(1, 2, 256, 256, 64, F16, seed=3))
+    for causal in (False, True):
+        ref = P.naive_attention(Q.float(), K.float(), V.float(), causal)
+        got = M.flash_attention(Q, K, V, causal)
+        assert fo.rel_fro(ref.cpu(), got.cpu()) < 1e-3

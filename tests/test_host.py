@@ -104,6 +104,35 @@ def test_binding_asserts_like_reference_on_bad_inputs():
         M.flash_attention(q, q, q)
 
 
+def test_kv_shape_mismatch_is_rejected_before_any_launch():
+    # the kernels take B and H from Q; a K / V with fewer heads or batches would be read out of bounds
+    import My_FlashAttention_optimized as M
+    q = torch.randn(2, 4, 16, 64, dtype=torch.float16)
+    kv = torch.randn(2, 1, 16, 64, dtype=torch.float16)
+    for bad_k, bad_v in ((kv, kv), (q[:1], q[:1]), (q, q[:, :, :8]), (q, q.to(torch.bfloat16))):
+        with pytest.raises(AssertionError):
+            M._check_qkv(q, bad_k, bad_v)
+        with pytest.raises(AssertionError):           # the direct launchers check too, before allocating or launching
+            M.flash_attention_forward(q, bad_k, bad_v, False)
+        with pytest.raises(AssertionError):
+            M.flash_attention_backward(q, bad_k, bad_v, q, q, q[..., 0].float(), False)
+    M._check_qkv(q, kv.expand(2, 4, 16, 64), kv.expand(2, 4, 16, 64))   # the supported MQA form: expanded heads
+
+
+def test_misaligned_or_oversize_views_are_copied_not_passed_through():
+    import _mi355fa as fa
+    import My_FlashAttention_optimized as M
+    base = torch.zeros(2 * 4 * 16 * 64 + 8, dtype=torch.float16)
+    off = 1 if base.data_ptr() % 16 == 0 else 0
+    t = base[off + 0: off + 2 * 4 * 16 * 64].view(2, 4, 16, 64)            # contiguous, base 2 bytes off a 16-B boundary
+    if t.data_ptr() % 16:
+        assert t.is_contiguous() and not fa.strided_ok(t)
+        (c,) = M._in_place(t)
+        assert c.data_ptr() % 16 == 0 and c.is_contiguous() and torch.equal(c, t)
+    big = torch.empty(0, dtype=torch.float16, device="meta").as_strided((1, 1, 3, 64), (0, 0, 1 << 30, 1))  # 2 GiB rows
+    assert not fa.strided_ok(big)
+
+
 def test_verify_results_kat_and_return_value(capsys):
     from _util import load_kat
     import _verify_func as V
@@ -115,6 +144,25 @@ def test_verify_results_kat_and_return_value(capsys):
         assert ("Test Passed" in out) == case["passed"] == m["passed"]
         assert "Max Normalized Error (allclose-style)" in out
         assert abs(m["max_norm"] - case["max_norm"]) <= 6e-3 * case["max_norm"]
+
+
+def test_package_naive_attention_kat():
+    # a12: the PACKAGE's naive_attention (not the oracle's) against the KAT taken from the reference's function (P:130-144)
+    from _util import load_kat
+    import Performance_Comparison as P
+    n = 2 * 1 * 4 * 8
+    q = ((torch.arange(n) % 7 - 3) / 4.0).view(2, 1, 4, 8)
+    k = ((torch.arange(n) % 5 - 2) / 3.0).view(2, 1, 4, 8)
+    v = ((torch.arange(n) % 3 - 1) / 2.0).view(2, 1, 4, 8)
+    for case in load_kat()["naive"]:
+        o = P.naive_attention(q, k, v, case["causal"])
+        assert torch.allclose(o.flatten(), torch.tensor(case["o"]), atol=1e-6)
+        assert abs(o.sum().item() - case["sum"]) < 1e-5
+    sig = [(p.name, p.default) for p in inspect.signature(P.benchmark_attention).parameters.values()]
+    E = inspect.Parameter.empty
+    assert sig[:11] == [("provider", E), ("mode", E), ("B", E), ("H", E), ("S_q", E), ("S_k", E), ("D", E),
+                        ("is_causal", E), ("device", E), ("warmup", 10), ("repeat", 30)]          # P:9-21
+    assert [p for p in inspect.signature(P.timing).parameters] == ["run_fn", "warmup", "repeat"]   # P:111
 
 
 def test_host_modules_parse_on_py310_grammar():

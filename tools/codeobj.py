@@ -159,15 +159,17 @@ def kernels(lib_path=DEFAULT_LIB):
 
 
 def demangle_short(name):
-    """fa_bwd_dq_kernel<64,BF16,causal,3> style label from the mangled template instance."""
+    """fa_bwd_dq_kernel<64,BF16,true,3> style label from the mangled template instance."""
     import re
-    m = re.match(r"_ZN2fa\d+(\w+?)IL[ij](\d+)ENS_(\w+?)E(.*)EEv", name)
+    m = re.match(r"_ZN2fa\d+(\w+?_kernel)I(.*)EvNS_\d+\w+E$", name)
     if not m:
         return name
-    rest = re.findall(r"L([bij])(\d+)E", m.group(4))
-    args = [m.group(2), m.group(3)[1:] if m.group(3)[0].isdigit() else m.group(3)]
-    for kind, val in rest:
-        args.append(("true" if val == "1" else "false") if kind == "b" else val)
+    args = []
+    for kind, val, typ in re.findall(r"L([bij])(\d+)E|NS_\d+([A-Z0-9]+)E", m.group(2)):
+        if typ:
+            args.append(typ)
+        else:
+            args.append(("true" if val == "1" else "false") if kind == "b" else val)
     return "%s<%s>" % (m.group(1), ",".join(args))
 
 
