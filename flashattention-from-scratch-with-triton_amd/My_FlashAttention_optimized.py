@@ -12,45 +12,23 @@ public names, argument order and defaults --
 -- but the three Triton launches are three calls into libmi355fa.so (hand-written gfx950
 HIP kernels, C ABI in include/mi355fa.h) on PyTorch's current stream.  PyTorch only
 provides device memory, the stream and autograd.  There is no Triton and no fallback: on
-a machine without the built library the import fails.
+a machine without the built libraries the import fails.
+
+Host path: the launchers and the autograd function that `flash_attention` uses live in
+_mi355fa_torch.so (csrc/torch_binding.cpp: the same checks / allocations / C-ABI calls as the
+Python code below, without the interpreter -- at the reference's S = 512 benchmark points a
+Python autograd.Function costs more host time per step than the three kernels take).
+`FlashAttentionFunction` keeps the reference's Python class (same forward / backward
+signatures, M:130-166) on top of the same launchers; _mi355fa.py is the ctypes view of the
+C ABI used by the tools and the tests that drive the library directly.
 """
 import torch
 import torch.nn.functional as F
 
 import _mi355fa as _fa
+import _mi355fa_torch as _ext   # raises if the binding was not built (make -C csrc)
 
 _DTYPES = {torch.float16: _fa.FP16, torch.bfloat16: _fa.BF16}
-_fwd, _bwd_dq, _bwd_dkv = _fa.lib.fa_fwd_strided, _fa.lib.fa_bwd_dq_strided, _fa.lib.fa_bwd_dkv_strided
-
-
-try:   # the raw hipStream_t of PyTorch's current stream without building a torch.cuda.Stream object (~3 us per call)
-    _raw_stream = torch._C._cuda_getCurrentRawStream
-except AttributeError:  # pragma: no cover - older / newer PyTorch without the private accessor
-    _raw_stream = None
-
-
-def _stream(index=None):
-    if _raw_stream is not None and index is not None:
-        return _raw_stream(index)
-    return torch.cuda.current_stream().cuda_stream
-
-
-class _OnDevice:
-    """`with torch.cuda.device(d)` only when `d` is not already current (the context manager costs ~5 us per call,
-    which is most of the host time at the reference's small benchmark shapes)."""
-    __slots__ = ("ctx",)
-
-    def __init__(self, device):
-        self.ctx = None if device.index == torch.cuda.current_device() else torch.cuda.device(device)
-
-    def __enter__(self):
-        if self.ctx is not None:
-            self.ctx.__enter__()
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-
 
 def _in_place(*tensors):
     """The reference makes every input contiguous (M:138-140,156): a 64 MiB copy per tensor at the headline size
@@ -82,52 +60,13 @@ def _check_qkv(Q, K, V):
 
 def flash_attention_forward(Q, K, V, is_causal):
     """Allocate O / LSE and enqueue the forward kernel (M:14-60).  Q, K, V: contiguous, or strided views accepted
-    by _mi355fa.strided_ok with K and V sharing their sequence stride."""
-    _check_qkv(Q, K, V)
-    B, H, S_q, D = Q.shape
-    _, _, S_k, _ = K.shape
-    O = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
-    LSE = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
-    sq, sk, sv = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V)   # keep the ctypes arrays alive over the call
-    with _OnDevice(Q.device):
-        rc = _fwd(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(), LSE.data_ptr(),
-                  B, H, S_q, S_k, D, _DTYPES[Q.dtype], 1 if is_causal else 0, 1 / (D ** 0.5), _stream(Q.device.index))
-    if rc:
-        _fa.check(rc, "fa_fwd")
-    return O, LSE
+    by _mi355fa.strided_ok with K and V sharing their sequence stride.  Runs in _mi355fa_torch.forward_launch."""
+    return _ext.forward_launch(Q, K, V, bool(is_causal))
 
 
 def flash_attention_backward(Q, K, V, O, dO, LSE, is_causal):
-    """Allocate dQ/dK/dV/delta and enqueue dQ (+delta) then dK/dV (M:62-128)."""
-    _check_qkv(Q, K, V)
-    assert O.shape == Q.shape and dO.shape == Q.shape and LSE.shape == Q.shape[:3]
-    assert O.device == dO.device == LSE.device == Q.device
-    B, H, S_q, D = Q.shape
-    _, _, S_k, _ = K.shape
-    if S_q == S_k:   # self-attention: one allocation for the three gradients (M:71-73 makes three)
-        dQ, dK, dV = torch.empty((3, B, H, S_q, D), dtype=Q.dtype, device=Q.device).unbind(0)
-    else:
-        dQ = torch.empty((B, H, S_q, D), dtype=Q.dtype, device=Q.device)
-        dK, dV = torch.empty((2, B, H, S_k, D), dtype=Q.dtype, device=Q.device).unbind(0)
-    delta = torch.empty((B, H, S_q), dtype=torch.float32, device=Q.device)
-    dt, causal, scale = _DTYPES[Q.dtype], 1 if is_causal else 0, 1 / (D ** 0.5)
-    if not O.is_contiguous() or O.data_ptr() & 15:   # normally the tensor flash_attention_forward returned
-        O = O.clone(memory_format=torch.contiguous_format)
-    sq, sk, sv, sdo = _fa.strides3(Q), _fa.strides3(K), _fa.strides3(V), _fa.strides3(dO)
-    with _OnDevice(Q.device):
-        s = _stream(Q.device.index)
-        rc = _bwd_dq(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, O.data_ptr(),
-                     dO.data_ptr(), sdo, LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
-                     B, H, S_q, S_k, D, dt, causal, scale, s)
-        if rc:
-            _fa.check(rc, "fa_bwd_dq")
-        # same stream, after dQ: the dK/dV kernel reads the delta the dQ kernel wrote (K:376)
-        rc = _bwd_dkv(Q.data_ptr(), sq, K.data_ptr(), sk, V.data_ptr(), sv, dO.data_ptr(), sdo,
-                      LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                      B, H, S_q, S_k, D, dt, causal, scale, s)
-        if rc:
-            _fa.check(rc, "fa_bwd_dkv")
-    return dQ, dK, dV
+    """Allocate dQ/dK/dV/delta and enqueue dQ (+delta) then dK/dV (M:62-128): _mi355fa_torch.backward_launch."""
+    return _ext.backward_launch(Q, K, V, O, dO, LSE, bool(is_causal))
 
 
 class FlashAttentionFunction(torch.autograd.Function):
@@ -160,7 +99,8 @@ class FlashAttentionFunction(torch.autograd.Function):
 
 
 def flash_attention(Q, K, V, is_causal=False):
-    return FlashAttentionFunction.apply(Q, K, V, is_causal)
+    """M:169-170.  The autograd function behind it is the C++ twin of FlashAttentionFunction (torch_binding.cpp)."""
+    return _ext.flash_attention(Q, K, V, bool(is_causal))
 
 
 def sdpa_reference(Q, K, V, is_causal):

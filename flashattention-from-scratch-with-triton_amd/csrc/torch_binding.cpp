@@ -1,0 +1,198 @@
+// Host-side binding of libmi355fa.so for PyTorch-ROCm: the launchers and the autograd function of
+// My_FlashAttention_optimized.py (reference: code/My_FlashAttention_optimized.py:14-170) written against the C ABI of
+// include/mi355fa.h.  PyTorch supplies device memory, the current stream and the autograd graph -- nothing else.
+//
+// Why this exists beside the ctypes binding (_mi355fa.py, still used by tools and by the tests that drive the C ABI
+// directly): at the reference's small benchmark shapes (B=4, H=8, S=512) a fwd+bwd step is ~35 us of kernels, and a
+// Python autograd.Function costs ~125 us of host time per step (Function.apply, ctx bookkeeping, the backward running
+// on the autograd thread under the GIL, ctypes argument marshalling) against ~80 us for torch's own C++ SDPA.  Here the
+// same sequence -- checks, torch::empty outputs, fa_fwd_strided / fa_bwd_dq_strided / fa_bwd_dkv_strided on the current
+// stream -- runs without the interpreter.
+//
+// Built by csrc/Makefile with g++ (host code only; no device code here) into _mi355fa_torch.so next to libmi355fa.so.
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
+#include <torch/extension.h>
+
+#include <tuple>
+
+#include "../../include/mi355fa.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+
+// The reference raises AssertionError on bad arguments (M:133-136); keep the exception type.
+[[noreturn]] void assertion(const char* msg) {
+  PyErr_SetString(PyExc_AssertionError, msg);
+  throw pybind11::error_already_set();
+}
+#define FA_ASSERT(cond, msg) \
+  do {                       \
+    if (!(cond)) assertion(msg); \
+  } while (0)
+
+void check_rc(int rc, const char* what) {
+  if (rc != 0) {
+    std::string m = std::string(what) + " failed (code " + std::to_string(rc) + "): " + fa_last_error();
+    throw std::runtime_error(m);
+  }
+}
+
+// _mi355fa.strided_ok: can the kernels read `t` in place?
+bool strided_ok(const Tensor& t) {
+  if (reinterpret_cast<uintptr_t>(t.data_ptr()) % 16) return false;
+  if (t.is_contiguous()) return true;
+  if (t.stride(3) != 1) return false;
+  if (t.stride(2) < t.size(3)) return false;
+  if (t.size(2) > 1 && t.stride(2) % 8) return false;
+  if ((t.size(2) - 1) * t.stride(2) * 2 + 2 * t.size(3) > ((1ll << 31) - 1)) return false;
+  for (int i = 0; i < 2; ++i)
+    if (t.size(i) != 1 && (t.stride(i) < 0 || t.stride(i) % 8 != 0)) return false;
+  return true;
+}
+Tensor in_place(const Tensor& t) { return strided_ok(t) ? t : t.clone(at::MemoryFormat::Contiguous); }
+
+// element strides {batch, head, seq} for the C ABI, or nullptr for a contiguous tensor (_mi355fa.strides3)
+struct Strides3 {
+  long long v[3];
+  const long long* ptr;
+  explicit Strides3(const Tensor& t) {
+    if (t.is_contiguous()) {
+      ptr = nullptr;
+      return;
+    }
+    v[0] = t.size(0) > 1 ? t.stride(0) : 0;
+    v[1] = t.size(1) > 1 ? t.stride(1) : 0;
+    v[2] = t.size(2) > 1 ? t.stride(2) : t.size(3);
+    ptr = v;
+  }
+};
+
+int dtype_code(const Tensor& t) {
+  if (t.scalar_type() == at::kHalf) return MI355FA_FP16;
+  if (t.scalar_type() == at::kBFloat16) return MI355FA_BF16;
+  assertion("dtype must be float16 or bfloat16");
+}
+
+void check_qkv(const Tensor& Q, const Tensor& K, const Tensor& V) {
+  FA_ASSERT(Q.dim() == 4 && K.dim() == 4 && V.dim() == 4, "Q, K, V must be [B, H, S, D]");
+  FA_ASSERT(K.size(0) == Q.size(0) && K.size(1) == Q.size(1),
+            "K must have Q's batch and head counts (expand shared K/V heads)");
+  FA_ASSERT(V.sizes() == K.sizes(), "K and V must have the same shape");
+  FA_ASSERT(Q.size(3) == K.size(3), "Q, K, V must share the head dim");
+  FA_ASSERT(Q.device() == K.device() && Q.device() == V.device(), "Q, K, V must be on the same device");
+  FA_ASSERT(Q.scalar_type() == K.scalar_type() && Q.scalar_type() == V.scalar_type(), "Q, K, V must share their dtype");
+}
+
+void* current_stream(const Tensor& t) {
+  return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
+}
+
+// flash_attention_forward (M:14-60): allocate O / LSE, enqueue.  Inputs: contiguous or strided_ok views, K and V sharing
+// their sequence stride.
+std::tuple<Tensor, Tensor> forward_launch(const Tensor& Q, const Tensor& K, const Tensor& V, bool causal) {
+  check_qkv(Q, K, V);
+  FA_ASSERT(Q.is_cuda(), "Q, K, V must be device tensors");
+  const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
+  const int dt = dtype_code(Q);
+  c10::OptionalDeviceGuard guard(Q.device());
+  Tensor O = torch::empty({B, H, Sq, D}, Q.options());
+  Tensor LSE = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
+  Strides3 sq(Q), sk(K), sv(V);
+  check_rc(fa_fwd_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(),
+                          (float*)LSE.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
+                          (float)(1.0 / std::sqrt((double)D)), current_stream(Q)),
+           "fa_fwd");
+  return {O, LSE};
+}
+
+// flash_attention_backward (M:62-128): allocate dQ / dK / dV / delta, enqueue dQ (+delta) then dK/dV on the same stream
+// (the dK/dV kernel reads the delta the dQ kernel wrote, K:376).
+std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& O_,
+                                                   const Tensor& dO, const Tensor& LSE, bool causal) {
+  check_qkv(Q, K, V);
+  FA_ASSERT(Q.is_cuda(), "Q, K, V must be device tensors");
+  FA_ASSERT(O_.sizes() == Q.sizes() && dO.sizes() == Q.sizes(), "O and dO must have Q's shape");
+  FA_ASSERT(LSE.dim() == 3 && LSE.size(0) == Q.size(0) && LSE.size(1) == Q.size(1) && LSE.size(2) == Q.size(2),
+            "LSE must be [B, H, S_q]");
+  FA_ASSERT(O_.device() == Q.device() && dO.device() == Q.device() && LSE.device() == Q.device(),
+            "O, dO, LSE must be on Q's device");
+  FA_ASSERT(LSE.scalar_type() == at::kFloat && LSE.is_contiguous(), "LSE must be contiguous float32");
+  const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
+  const int dt = dtype_code(Q);
+  c10::OptionalDeviceGuard guard(Q.device());
+  Tensor O = (O_.is_contiguous() && reinterpret_cast<uintptr_t>(O_.data_ptr()) % 16 == 0)
+                 ? O_
+                 : O_.clone(at::MemoryFormat::Contiguous);
+  Tensor dQ, dK, dV;
+  if (Sq == Sk) {  // self-attention: one allocation for the three gradients (M:71-73 makes three)
+    Tensor g = torch::empty({3, B, H, Sq, D}, Q.options());
+    dQ = g.select(0, 0);
+    dK = g.select(0, 1);
+    dV = g.select(0, 2);
+  } else {
+    dQ = torch::empty({B, H, Sq, D}, Q.options());
+    Tensor g = torch::empty({2, B, H, Sk, D}, Q.options());
+    dK = g.select(0, 0);
+    dV = g.select(0, 1);
+  }
+  Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
+  Strides3 sq(Q), sk(K), sv(V), sdo(dO);
+  void* st = current_stream(Q);
+  const float scale = (float)(1.0 / std::sqrt((double)D));
+  check_rc(fa_bwd_dq_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(), dO.data_ptr(),
+                             sdo.ptr, (const float*)LSE.data_ptr(), dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H,
+                             (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
+           "fa_bwd_dq");
+  check_rc(fa_bwd_dkv_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, dO.data_ptr(), sdo.ptr,
+                              (const float*)LSE.data_ptr(), (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                              (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
+           "fa_bwd_dkv");
+  return {dQ, dK, dV};
+}
+
+// FlashAttentionFunction (M:130-166)
+class FlashAttnFn : public torch::autograd::Function<FlashAttnFn> {
+ public:
+  static Tensor forward(AutogradContext* ctx, const Tensor& Q, const Tensor& K, const Tensor& V, bool is_causal) {
+    FA_ASSERT(Q.is_cuda() && K.is_cuda() && V.is_cuda(), "Q, K, V must be device tensors");
+    FA_ASSERT(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kBFloat16, "dtype must be float16 or bfloat16");
+    check_qkv(Q, K, V);
+    FA_ASSERT(Q.size(3) == 64 || Q.size(3) == 128, "head dim must be 64 or 128");
+    // no copy for views the kernels can read in place (M:138-140 copies every non-contiguous input)
+    Tensor Q_ = in_place(Q), K_ = in_place(K), V_ = in_place(V);
+    if (K_.size(2) > 1 && K_.stride(2) != V_.stride(2)) {  // the kernels use one row stride for the K/V pair
+      K_ = K_.contiguous();
+      V_ = V_.contiguous();
+    }
+    auto out = forward_launch(Q_, K_, V_, is_causal);
+    ctx->save_for_backward({Q_, K_, V_, std::get<0>(out), std::get<1>(out)});
+    ctx->saved_data["is_causal"] = is_causal;
+    return std::get<0>(out);
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grads) {
+    auto s = ctx->get_saved_variables();
+    const bool causal = ctx->saved_data["is_causal"].toBool();
+    Tensor dO = in_place(grads[0]);
+    auto g = backward_launch(s[0], s[1], s[2], s[3], dO, s[4], causal);
+    return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor()};
+  }
+};
+
+Tensor flash_attention(const Tensor& Q, const Tensor& K, const Tensor& V, bool is_causal) {
+  return FlashAttnFn::apply(Q, K, V, is_causal);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_mi355fa_torch, m) {
+  m.doc() = "C++ launchers and autograd function over libmi355fa.so (see My_FlashAttention_optimized.py)";
+  m.def("flash_attention", &flash_attention, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
+        pybind11::arg("is_causal") = false);
+  m.def("forward_launch", &forward_launch);
+  m.def("backward_launch", &backward_launch);
+  m.def("abi_version", []() { return fa_abi_version(); });
+}

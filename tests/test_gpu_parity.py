@@ -166,6 +166,31 @@ def test_autograd_path_and_strided_inputs():
     assert o.dtype == F16 and q.grad.shape == q.shape
 
 
+def test_python_autograd_class_and_cpp_autograd_function_agree():
+    """FlashAttentionFunction (the reference's Python class, M:130-166) and flash_attention (its C++ twin in
+    _mi355fa_torch.so) run the same launchers: bit-identical outputs and gradients, contiguous and strided inputs."""
+    M = _host()
+    for causal in (False, True):
+        Q, K, V, dO = (x.cuda() for x in rand_inputs(2, 3, 320, 448, 64, BF16, seed=13))
+        for view in (False, True):
+            outs = []
+            for fn in (M.flash_attention, lambda q, k, v, c: M.FlashAttentionFunction.apply(q, k, v, c)):
+                mk = (lambda x: x.transpose(1, 2).contiguous().transpose(1, 2)) if view else (lambda x: x.clone())
+                q, k, v = (mk(x).requires_grad_(True) for x in (Q, K, V))
+                o = fn(q, k, v, causal)
+                o.backward(mk(dO))
+                outs.append((o.detach(), q.grad, k.grad, v.grad))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
+    # no grad needed -> no graph, same numbers
+    with torch.no_grad():
+        assert torch.equal(M.flash_attention(Q, K, V, True), M.flash_attention_forward(Q, K, V, True)[0])
+    # only some inputs need a gradient
+    q, k, v = Q.clone().requires_grad_(True), K.clone(), V.clone()
+    M.flash_attention(q, k, v, False).backward(dO)
+    assert q.grad is not None and k.grad is None
+
+
 @pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
 def test_rescale_branch_is_exercised_by_a_late_spike(impl, dtype):
     """Online-softmax max must jump in a LATE tile: one key far down the sequence dominates one query

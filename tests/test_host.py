@@ -35,6 +35,19 @@ def test_library_exports_every_declared_symbol():
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
 
+def test_torch_binding_loads_and_matches_the_abi():
+    import _mi355fa as fa
+    import _mi355fa_torch as ext
+    assert ext.abi_version() == fa.ABI_VERSION == 2
+    for name in ("flash_attention", "forward_launch", "backward_launch"):
+        assert callable(getattr(ext, name)), name
+    q = torch.randn(1, 1, 8, 64, dtype=torch.float16)
+    with pytest.raises(AssertionError, match="device tensors"):       # M:133, before any allocation or launch
+        ext.flash_attention(q, q, q, True)
+    with pytest.raises(AssertionError, match="same shape"):
+        ext.forward_launch(q, q, q[:, :, :4], False)
+
+
 def test_argument_errors_are_rejected_before_launch():
     import _mi355fa as fa
     buf = (ctypes.c_char * 4096)()
