@@ -2,11 +2,15 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/mi355fa.h"
 #include "fa_kernels.h"
 
 namespace fa {
-int g_force_fwd = 0, g_force_dq = 0, g_force_dkv = 0;  // 0 = selection rule of fa_kernels.h
+// 0 = selection table of fa_kernels.h.  Written only by fa_debug_force_impl() (tests, A/B tools, the tuner); relaxed
+// atomics so that a thread flipping them while another launches is a benign race, not undefined behaviour.
+std::atomic<int> g_force_fwd{0}, g_force_dq{0}, g_force_dkv{0};
 }
 
 namespace {
@@ -64,9 +68,17 @@ int fa_abi_version(void) { return MI355FA_ABI_VERSION; }
 
 // Not part of the public header: pin the schedule family per kernel (0 = automatic rule); tests and A/B tools.
 void fa_debug_force_impl(int fwd, int dq, int dkv) {
-  fa::g_force_fwd = fwd;
-  fa::g_force_dq = dq;
-  fa::g_force_dkv = dkv;
+  fa::g_force_fwd.store(fwd, std::memory_order_relaxed);
+  fa::g_force_dq.store(dq, std::memory_order_relaxed);
+  fa::g_force_dkv.store(dkv, std::memory_order_relaxed);
+}
+
+// Not part of the public header: which schedule family a contiguous launch of this shape takes (kernel 0 = forward,
+// 1 = dQ, 2 = dK/dV), after the generated table (fa_table.h), the validity fallbacks and any forced override.
+int fa_debug_pick(int kernel, int D, int dtype, int causal, int B, int H, int S_q, int S_k) {
+  if (kernel == 0) return fa::pick_fwd_impl(fa::g_force_fwd, D, dtype, B, H, S_q, S_k, causal != 0, true);
+  if (kernel == 1) return fa::pick_dq_impl(fa::g_force_dq, D, dtype, B, H, S_q, S_k, causal != 0, true);
+  return fa::pick_dkv_impl(fa::g_force_dkv, D, dtype, B, H, S_q, S_k, causal != 0);
 }
 
 // Not part of the public header: diagnostic hook used by tools/stamps.py with -DFA_STAMPS builds.

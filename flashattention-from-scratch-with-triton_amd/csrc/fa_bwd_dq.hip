@@ -261,10 +261,9 @@ hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s); 
 hipError_t launch_bwd_dq_v3(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v3.hip
 
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  if (D == 64 && pick_dq3(g_force_dq, p.Sk)) return launch_bwd_dq_v3(p, dtype, causal, s);
-  // family 2 reads contiguous operands only; strided views always take family 1
-  if (p.all_contiguous(D) && pick_fwd_dq_impl(g_force_dq, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
-    return launch_bwd_dq_v2(p, dtype, causal, s);
+  const int impl = pick_dq_impl(g_force_dq, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.all_contiguous(D));
+  if (impl == 3) return launch_bwd_dq_v3(p, dtype, causal, s);
+  if (impl == 2) return launch_bwd_dq_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
 #define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))

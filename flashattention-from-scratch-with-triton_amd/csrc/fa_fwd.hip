@@ -428,8 +428,7 @@ static hipError_t launch(const FwdParams& p, hipStream_t s) {
 hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v2.hip
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  // family 2 reads contiguous operands only; strided views always take family 1
-  if (p.all_contiguous(D) && pick_fwd_dq_impl(g_force_fwd, D, p.B, p.H, p.Sq, causal != 0, dtype == 1 && BF16::kFoldScale) == 2)
+  if (pick_fwd_impl(g_force_fwd, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.all_contiguous(D)) == 2)
     return launch_fwd_v2(p, dtype, causal, s);
   p.nq_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.nq_tiles, (long)p.B * p.H);

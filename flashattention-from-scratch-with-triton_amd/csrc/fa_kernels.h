@@ -2,6 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
+#include "fa_table.h"
+
 namespace fa {
 
 // Byte strides of one [B, H, S, D] INPUT operand whose D dimension is contiguous: batch, head, row.
@@ -52,35 +56,46 @@ struct BwdParams {
   }
 };
 
-// ---- schedule selection (the counterpart of the reference's autotune key (S_q, S_k, D, is_causal),
-// K:18-32): a static rule per kernel instead of a run-time search.  Two schedule families exist for D = 64:
-//   1 = 128-row (128-key) workgroups, 32 rows per wave, up to 3 waves per SIMD  (also the only D = 128 path)
-//   2 = 256-row workgroups, 64 rows per wave sharing every K/V fragment (forward, dQ: D = 64 only); 128-row Q/dO
-//       tiles and the hand-ordered pipeline (dK/dV: D = 64 and 128)
-// Measured on MI355X (profiles/r01_schedule_selection.txt): family 1 wins on small grids and on causal
-// forward / dQ; family 2 wins on large non-causal grids (fp16 forward, dQ) and for dK/dV from S_q = 256 up.
-// fa_debug_force_impl() (not in the public header) overrides the rule for tests and A/B runs; 0 = rule.
-extern int g_force_fwd, g_force_dq, g_force_dkv;
-// `fold`: the bf16 kernels, whose family-1 hot loops start the score chain from the row constant (fa_common.h
-// kFoldScale): family 1 then wins on every grid measured (non-causal B4 H32 S4096: forward 1040 vs 1007 TFLOPS,
-// dQ at three workgroups per CU 1161 vs 1135; S8192: forward 1052 vs 1018).
-inline int pick_fwd_dq_impl(int forced, int D, int B, int H, int Sq, bool causal, bool fold = false) {
-  if (D != 64) return 1;
-  if (forced) return forced;
-  if (fold) return 1;
-  const long tiles256 = (Sq + 255) / 256;
-  const long wgs2 = (long)B * H * (causal ? (tiles256 + 1) / 2 : tiles256);
-  return (!causal && wgs2 >= 512) ? 2 : 1;
+// ---- schedule selection: the counterpart of the reference's autotune key (S_q, S_k, D, is_causal), K:18-32 --------
+// A table generated offline (tools/tune.py -> fa_table.h) instead of a run-time search.  Schedule families:
+//   forward   1 = fa_fwd.hip      128-row workgroups, 32 rows per wave, up to 3 waves per SIMD  (D = 64, 128)
+//             2 = fa_fwd_v2.hip   256-row workgroups, 64 rows per wave sharing every K/V fragment (D = 64, contiguous)
+//   dQ        1 = fa_bwd_dq.hip   as forward 1;  2 = fa_bwd_dq_v2.hip as forward 2;
+//             3 = fa_bwd_dq_v3.hip  128-row workgroups, per-wave three-stage software pipeline (D = 64)
+//   dK/dV     1 = fa_bwd_dkv.hip  128-key workgroups, 64-row Q/dO tiles;
+//             2 = fa_bwd_dkv_v2.hip  128-row Q/dO tiles, hand-ordered pipeline (D = 64, 128)
+// The table is keyed on (kernel, D, dtype, causal, B*H bucket, S bucket); a family the launch cannot use (strided
+// views for the 64-rows-per-wave kernels, a head dim it does not exist for) falls back to family 1.
+// fa_debug_force_impl() (not in the public header) overrides the table for tests, A/B runs and the tuner; 0 = table.
+extern std::atomic<int> g_force_fwd, g_force_dq, g_force_dkv;
+
+inline int nearest_log2_bucket(long v, const int* buckets, int n) {
+  int best = 0;
+  for (int i = 1; i < n; ++i)   // buckets are powers of two: nearest in log2 = compare against the geometric mean
+    if ((double)v * v > (double)buckets[i - 1] * buckets[i]) best = i;
+  return best;
 }
-// dQ family 3 (fa_bwd_dq_v3.hip, D = 64): the per-wave three-stage pipeline.
-inline bool pick_dq3(int forced, int Sk) {
-  if (forced) return forced == 3;
-  return false;
-}
-inline int pick_dkv_impl(int forced, int D, int Sq) {
+enum { kKernelFwd = 0, kKernelDq = 1, kKernelDkv = 2 };
+inline int table_family(int kernel, int D, int dtype, bool causal, long bh, long S) {
   if (D != 64 && D != 128) return 1;
-  if (forced) return forced;
-  return Sq >= 256 ? 2 : 1;  // profiles/r01_schedule_selection.txt: the pipelined family 2 wins from S = 256 up
+  return table::kFamily[kernel][D == 128][dtype == 1][causal ? 1 : 0][nearest_log2_bucket(bh, table::kBH, table::kNumBH)]
+                       [nearest_log2_bucket(S, table::kS, table::kNumS)];
+}
+inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
+  int f = forced ? forced : table_family(kKernelFwd, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  if (f == 2 && (D != 64 || !contiguous)) f = 1;
+  return f == 2 ? 2 : 1;
+}
+inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
+  int f = forced ? forced : table_family(kKernelDq, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  if (f == 2 && (D != 64 || !contiguous)) f = 1;
+  if (f == 3 && D != 64) f = 1;
+  return (f == 2 || f == 3) ? f : 1;
+}
+inline int pick_dkv_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal) {
+  if (D != 64 && D != 128) return 1;
+  const int f = forced ? forced : table_family(kKernelDkv, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  return f == 2 ? 2 : 1;
 }
 
 // Causal tile pairing equalises the work per workgroup but halves the number of workgroups: worth it as

@@ -78,6 +78,32 @@ def test_argument_errors_are_rejected_before_launch():
     assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, None, *args) == -1
 
 
+def test_schedule_table_lookup_and_override():
+    """The generated shape -> schedule-family table (csrc/fa_table.h, tools/tune.py; the counterpart of the reference's
+    autotune key (S_q, S_k, D, is_causal), K:18-32) answers for every shape, and fa_debug_force_impl overrides it."""
+    import _mi355fa as fa
+    raw = ctypes.CDLL(fa.LIB_PATH)
+    pick, force = raw.fa_debug_pick, raw.fa_debug_force_impl
+    pick.argtypes = [ctypes.c_int] * 8
+    force.argtypes = [ctypes.c_int] * 3
+    allowed = {0: {64: {1, 2}, 128: {1}}, 1: {64: {1, 2, 3}, 128: {1}}, 2: {64: {1, 2}, 128: {1, 2}}}
+    for kernel in range(3):
+        for D in (64, 128):
+            for dtype in (0, 1):
+                for causal in (0, 1):
+                    for (B, H, S) in ((1, 1, 1), (4, 8, 512), (4, 32, 4096), (64, 32, 8192), (1, 2, 100000)):
+                        assert pick(kernel, D, dtype, causal, B, H, S, S) in allowed[kernel][D]
+    try:
+        force(2, 3, 1)
+        assert pick(0, 64, 0, 0, 4, 32, 4096, 4096) == 2 and pick(0, 128, 0, 0, 4, 32, 4096, 4096) == 1
+        assert pick(1, 64, 1, 1, 4, 32, 4096, 4096) == 3 and pick(1, 128, 1, 1, 4, 32, 4096, 4096) == 1
+        assert pick(2, 64, 1, 1, 4, 32, 4096, 4096) == 1
+    finally:
+        force(0, 0, 0)
+    hdr = open(os.path.join(PKG, "csrc", "fa_table.h")).read()
+    assert hdr.startswith("// GENERATED by tools/tune.py") and "kFamily[3][2][2][2]" in hdr
+
+
 def test_strided_ok_accepts_bshd_views_and_rejects_the_rest():
     import _mi355fa as fa
     x = torch.zeros(2, 16, 4, 64, dtype=torch.float16)            # [B, S, H, D]

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Offline tuner: the counterpart of the reference's run-time autotuner (K:18-32, key (S_q, S_k, D, is_causal)).
+
+    python tools/tune.py --measure profiles/r02_tune.json      (on the GPU box: times every schedule family per key)
+    python tools/tune.py --emit profiles/r02_tune.json         (anywhere: writes csrc/fa_table.h from the measurements)
+    python tools/tune.py --emit-rule                           (anywhere: fa_table.h from round 1's hand rule, no data)
+
+Key = (kernel, head dim, dtype, causal, B*H bucket, S bucket); value = schedule family (fa_kernels.h).  For every key the
+tuner launches each candidate family through the C ABI with fa_debug_force_impl(), interleaved, and keeps the fastest by
+median.  The table is baked into libmi355fa.so: no search at run time, no state, no first-call cost.
+Not part of the product; nothing in the package imports it.
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "flashattention-from-scratch-with-triton_amd")
+TABLE_H = os.path.join(PKG, "csrc", "fa_table.h")
+
+BH_BUCKETS = [8, 32, 128, 512]                                  # B*H, nearest in log2
+S_BUCKETS = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]      # max(S_q, S_k), nearest in log2
+KERNELS = ["fwd", "dq", "dkv"]
+CANDIDATES = {"fwd": {64: [1, 2], 128: [1]}, "dq": {64: [1, 2, 3], 128: [1]}, "dkv": {64: [1, 2], 128: [1, 2]}}
+DTYPES = ["fp16", "bf16"]
+
+
+def rule_family(kernel, D, dtype, causal, bh, S):
+    """Round 1's hand-written rule (fa_kernels.h at 5d1bcd4), kept as the no-data default."""
+    if kernel == "dkv":
+        return 2 if S >= 256 else 1
+    if D != 64 or dtype == "bf16":
+        return 1
+    tiles256 = (S + 255) // 256
+    wgs2 = bh * ((tiles256 + 1) // 2 if causal else tiles256)
+    return 2 if (not causal and wgs2 >= 512) else 1
+
+
+def measure(out_path, rounds, reps):
+    sys.path.insert(0, PKG)
+    import torch
+    import _mi355fa as host
+    lib = host.lib
+    lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+    res = []
+    P = lambda t: t.data_ptr()
+    for D in (64, 128):
+        for dtype in DTYPES:
+            dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+            code = host.BF16 if dtype == "bf16" else host.FP16
+            for bh in BH_BUCKETS:
+                for S in S_BUCKETS:
+                    if bh * S * S > 128 * 16384 * 16384 // 16 or bh * S > 512 * 4096:   # keep a point under ~20 ms
+                        continue
+                    H = 8 if bh >= 8 else bh
+                    B = bh // H
+                    torch.manual_seed(0)
+                    Q, K, V, dO = (torch.randn(B, H, S, D, device="cuda", dtype=dt) for _ in range(4))
+                    O, dQ, dK, dV = (torch.empty_like(Q) for _ in range(4))
+                    LSE = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
+                    delta = torch.empty_like(LSE)
+                    st = torch.cuda.current_stream().cuda_stream
+                    sc = D ** -0.5
+                    for causal in (0, 1):
+                        fns = {
+                            "fwd": lambda: lib.fa_fwd(P(Q), P(K), P(V), P(O), P(LSE), B, H, S, S, D, code, causal, sc, st),
+                            "dq": lambda: lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, code, causal, sc, st),
+                            "dkv": lambda: lib.fa_bwd_dkv(P(Q), P(K), P(V), P(dO), P(LSE), P(delta), P(dK), P(dV), B, H, S, S, D, code, causal, sc, st),
+                        }
+                        lib.fa_debug_force_impl(0, 0, 0)
+                        assert fns["fwd"]() == 0 and fns["dq"]() == 0      # valid O / LSE / delta for the timed launches
+                        for ki, kern in enumerate(KERNELS):
+                            cands = CANDIDATES[kern][D]
+                            times = {c: [] for c in cands}
+                            n = max(3, min(reps, int(2e-3 / max(1e-6, 4 * bh * S * S * D * 1e-15)) + 3))
+                            for rnd in range(rounds + 1):
+                                for c in cands:
+                                    f = [0, 0, 0]
+                                    f[ki] = c
+                                    lib.fa_debug_force_impl(*f)
+                                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                    e0.record()
+                                    for _ in range(n):
+                                        rc = fns[kern]()
+                                    e1.record()
+                                    torch.cuda.synchronize()
+                                    assert rc == 0
+                                    if rnd:                       # round 0 = warm-up
+                                        times[c].append(e0.elapsed_time(e1) / n * 1e3)
+                            med = {c: statistics.median(v) for c, v in times.items()}
+                            best = min(med, key=med.get)
+                            res.append({"kernel": kern, "D": D, "dtype": dtype, "causal": causal, "bh": bh, "S": S,
+                                        "us": {str(c): round(v, 2) for c, v in med.items()}, "best": best})
+                            print("%-3s D%-3d %s %s BH%-3d S%-5d  %s  -> %d" % (
+                                kern, D, dtype, "causal" if causal else "full  ", bh, S,
+                                "  ".join("f%d %.1fus" % (c, v) for c, v in med.items()), best), flush=True)
+                        lib.fa_debug_force_impl(0, 0, 0)
+                    del Q, K, V, dO, O, dQ, dK, dV
+    json.dump({"bh_buckets": BH_BUCKETS, "s_buckets": S_BUCKETS, "points": res}, open(out_path, "w"), indent=0)
+    print("wrote", out_path)
+
+
+def emit(points, source):
+    tab = {}
+    for kern in KERNELS:
+        for D in (64, 128):
+            for dtype in DTYPES:
+                for causal in (0, 1):
+                    for bi, bh in enumerate(BH_BUCKETS):
+                        for si, S in enumerate(S_BUCKETS):
+                            tab[(kern, D, dtype, causal, bi, si)] = rule_family(kern, D, dtype, causal, bh, S)
+    measured = 0
+    if points:
+        # a family must win by > 2 % over the rule's choice to displace it (noise guard); unmeasured keys take the
+        # nearest measured S at the same B*H
+        by = {}
+        for p in points:
+            by[(p["kernel"], p["D"], p["dtype"], p["causal"], p["bh"], p["S"])] = p
+        for key in list(tab):
+            kern, D, dtype, causal, bi, si = key
+            bh = BH_BUCKETS[bi]
+            cand = [S for S in S_BUCKETS if (kern, D, dtype, causal, bh, S) in by]
+            if not cand:
+                continue
+            S = min(cand, key=lambda s: abs(S_BUCKETS.index(s) - si))
+            p = by[(kern, D, dtype, causal, bh, S)]
+            us = {int(k): v for k, v in p["us"].items()}
+            cur = tab[key] if tab[key] in us else min(us, key=us.get)
+            best = min(us, key=us.get)
+            tab[key] = best if us[best] < 0.98 * us[cur] else cur
+            measured += 1
+    lines = ["// GENERATED by tools/tune.py -- do not edit.  Source: %s" % source,
+             "// Schedule family per (kernel, head dim, dtype, causal, B*H bucket, S bucket): the baked counterpart of the",
+             "// reference's run-time autotuner (K:18-32).  Lookup: fa_kernels.h table_family().",
+             "#pragma once", "namespace fa {", "namespace table {",
+             "constexpr int kNumBH = %d, kNumS = %d;" % (len(BH_BUCKETS), len(S_BUCKETS)),
+             "constexpr int kBH[kNumBH] = {%s};" % ", ".join(map(str, BH_BUCKETS)),
+             "constexpr int kS[kNumS] = {%s};" % ", ".join(map(str, S_BUCKETS)),
+             "// [kernel: fwd, dq, dkv][D: 64, 128][dtype: fp16, bf16][causal][B*H bucket][S bucket]",
+             "constexpr unsigned char kFamily[3][2][2][2][kNumBH][kNumS] = {"]
+    for kern in KERNELS:
+        lines.append("  {  // %s" % kern)
+        for D in (64, 128):
+            lines.append("    {  // D = %d" % D)
+            for dtype in DTYPES:
+                lines.append("      {  // %s" % dtype)
+                for causal in (0, 1):
+                    rows = []
+                    for bi in range(len(BH_BUCKETS)):
+                        rows.append("{" + ", ".join(str(tab[(kern, D, dtype, causal, bi, si)]) for si in range(len(S_BUCKETS))) + "}")
+                    lines.append("        {%s},  // %s" % (", ".join(rows), "causal" if causal else "full"))
+                lines.append("      },")
+            lines.append("    },")
+        lines.append("  },")
+    lines += ["};", "}  // namespace table", "}  // namespace fa", ""]
+    open(TABLE_H, "w").write("\n".join(lines))
+    print("wrote %s (%d keys from measurements, %d from the rule)" % (TABLE_H, measured, len(tab) - measured))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--measure")
+    ap.add_argument("--emit")
+    ap.add_argument("--emit-rule", action="store_true")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=30)
+    a = ap.parse_args()
+    if a.measure:
+        measure(a.measure, a.rounds, a.reps)
+    if a.emit:
+        emit(json.load(open(a.emit))["points"], os.path.relpath(a.emit, ROOT))
+    if a.emit_rule:
+        emit(None, "round 1 hand rule (no measurements)")
