@@ -143,3 +143,4 @@ if __name__ == '__main__':
                                                     is_causal=is_causal, device=DEVICE, dtype=dt)
                     result.append(round(tflops, 1))
                 print("D=%d %s %s %-8s %s" % (D, "causal" if is_causal else "full", mode, provider, result), flush=True)
+    print("# torch SDPA backend of the 'pytorch' provider: %s" % last_sdpa_backend(), flush=True)
