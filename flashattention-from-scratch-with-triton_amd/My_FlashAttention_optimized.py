@@ -103,6 +103,18 @@ def flash_attention(Q, K, V, is_causal=False):
     return _ext.flash_attention(Q, K, V, bool(is_causal))
 
 
+def flash_attention_varlen(Q, K, V, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal=False):
+    """Variable-length attention over PACKED sequences -- the extension the reference leaves as an exercise
+    (Phase_6.md:119-178: "concatenate the batch into one long sequence and record where each sequence starts").
+
+    Q: [total_q, H, D], K, V: [total_k, H, D] (fp16 / bf16, device); cu_seqlens_*: int32 device vectors of batch + 1
+    prefix sums starting at 0; max_seqlen_*: Python ints >= the longest sequence (they size the launch grid).  Returns
+    O [total_q, H, D]; differentiable w.r.t. Q, K, V.  Each sequence attends to itself only; is_causal applies each
+    sequence's own top-left aligned mask.  No padding is computed: workgroups beyond a sequence's length exit at once."""
+    return _ext.flash_attention_varlen(Q, K, V, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), int(max_seqlen_k),
+                                       bool(is_causal))
+
+
 def sdpa_reference(Q, K, V, is_causal):
     """torch SDPA on the device, fp16/bf16 (the reference pins the FLASH backend, M:178;
     here whatever backend this PyTorch-ROCm build selects)."""

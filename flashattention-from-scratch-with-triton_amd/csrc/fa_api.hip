@@ -60,6 +60,29 @@ int make_layout(const char* fn, const long long* st, int H, int S, int D, fa::Te
   return 0;
 }
 
+// the reference's output convention: contiguous [B, H, S, D] O / dQ / dK / dV, [B, H, S_q] LSE / delta
+void set_contiguous_outputs(fa::BwdParams* p, int H, int Sq, int Sk, int D) {
+  p->lo = p->ldq = fa::contiguous_layout(H, Sq, D);
+  p->ldk = p->ldv = fa::contiguous_layout(H, Sk, D);
+  p->lse_sb = (long long)H * Sq;
+  p->lse_sh = Sq;
+}
+
+// packed [total tokens, H, D] rows (varlen): no batch stride (the cu_seqlens arrays place each sequence), head stride D
+fa::TensorLayout packed_layout(int H, int D) { return fa::TensorLayout{0, (long long)D * 2, H * D * 2}; }
+
+int check_varlen(const char* fn, const int* cu_q, const int* cu_k, int batch, int H, int total_q, int total_k, int max_q,
+                 int max_k, int D, int dtype) {
+  if (!cu_q || !cu_k) return fail(MI355FA_ERR_NULL, "%s: NULL cu_seqlens", fn);
+  if (total_q < 1 || total_k < 1 || max_q > total_q || max_k > total_k)
+    return fail(MI355FA_ERR_SHAPE, "%s: need 1 <= max_seqlen <= total tokens", fn);
+  if (max_q < 1 || max_k < 1 || batch < 1) return fail(MI355FA_ERR_SHAPE, "%s: batch and max_seqlen must be >= 1", fn);
+  // 32-bit buffer offsets are used INSIDE one sequence (rows are H*D*2 bytes apart); the packed tensors may be larger
+  if ((long long)max_q * H * D * 2 > (1ll << 31) - 1 || (long long)max_k * H * D * 2 > (1ll << 31) - 1)
+    return fail(MI355FA_ERR_SHAPE, "%s: one packed sequence exceeds 2^31 bytes", fn);
+  return check_common(fn, batch, H, max_q, max_k, D, dtype);
+}
+
 }  // namespace
 
 extern "C" {
@@ -102,6 +125,9 @@ int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, con
   if (int rc = make_layout("fa_fwd", k_strides, H, S_k, D, &p.lk)) return rc;
   if (int rc = make_layout("fa_fwd", v_strides, H, S_k, D, &p.lv)) return rc;
   if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_fwd");
+  p.lo = fa::contiguous_layout(H, S_q, D);
+  p.lse_sb = (long long)H * S_q;
+  p.lse_sh = S_q;
   hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_fwd launch");
   return 0;
@@ -127,6 +153,7 @@ int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, 
   if (int rc = make_layout("fa_bwd_dq", v_strides, H, S_k, D, &p.lv)) return rc;
   if (int rc = make_layout("fa_bwd_dq", dout_strides, H, S_q, D, &p.ldo)) return rc;
   if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dq");
+  set_contiguous_outputs(&p, H, S_q, S_k, D);
   hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
   return 0;
@@ -153,6 +180,7 @@ int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k,
   if (int rc = make_layout("fa_bwd_dkv", v_strides, H, S_k, D, &p.lv)) return rc;
   if (int rc = make_layout("fa_bwd_dkv", dout_strides, H, S_q, D, &p.ldo)) return rc;
   if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dkv");
+  set_contiguous_outputs(&p, H, S_q, S_k, D);
   hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
   return 0;
@@ -163,6 +191,69 @@ int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, co
                void* stream) {
   return fa_bwd_dkv_strided(q, nullptr, k, nullptr, v, nullptr, dout, nullptr, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype,
                             causal, scale, stream);
+}
+
+// ---- variable-length ("varlen") entry points: packed [total, H, D] tensors + cu_seqlens (include/mi355fa.h) ----
+int fa_fwd_varlen(const void* q, const void* k, const void* v, void* o, float* lse, const int* cu_seqlens_q,
+                  const int* cu_seqlens_k, int batch, int H, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k,
+                  int D, int dtype, int causal, float scale, void* stream) {
+  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd_varlen");
+  if (int rc = check_varlen("fa_fwd_varlen", cu_seqlens_q, cu_seqlens_k, batch, H, total_q, total_k, max_seqlen_q,
+                            max_seqlen_k, D, dtype))
+    return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd_varlen");
+  fa::FwdParams p{q, k, v, o, lse, batch, H, max_seqlen_q, max_seqlen_k, scale, 0, g_dbg, 0};
+  p.lq = p.lk = p.lv = p.lo = packed_layout(H, D);
+  p.lse_sb = 0;
+  p.lse_sh = total_q;
+  p.vl = fa::VarLen{cu_seqlens_q, cu_seqlens_k};
+  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_fwd_varlen launch");
+  return 0;
+}
+
+static void fill_varlen_bwd(fa::BwdParams* p, const int* cu_q, const int* cu_k, int H, int total_q, int D) {
+  p->lq = p->lk = p->lv = p->ldo = p->lo = p->ldq = p->ldk = p->ldv = packed_layout(H, D);
+  p->lse_sb = 0;
+  p->lse_sh = total_q;
+  p->vl = fa::VarLen{cu_q, cu_k};
+}
+
+int fa_bwd_dq_varlen(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                     float* delta, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
+                     int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
+                     void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq_varlen");
+  if (int rc = check_varlen("fa_bwd_dq_varlen", cu_seqlens_q, cu_seqlens_k, batch, H, total_q, total_k, max_seqlen_q,
+                            max_seqlen_k, D, dtype))
+    return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
+      misaligned(dq) || misaligned(delta))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq_varlen");
+  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, batch, H, max_seqlen_q, max_seqlen_k, scale, 0, g_dbg, 0};
+  fill_varlen_bwd(&p, cu_seqlens_q, cu_seqlens_k, H, total_q, D);
+  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq_varlen launch");
+  return 0;
+}
+
+int fa_bwd_dkv_varlen(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                      void* dk, void* dv, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
+                      int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
+                      void* stream) {
+  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv_varlen");
+  if (int rc = check_varlen("fa_bwd_dkv_varlen", cu_seqlens_q, cu_seqlens_k, batch, H, total_q, total_k, max_seqlen_q,
+                            max_seqlen_k, D, dtype))
+    return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
+      misaligned(dk) || misaligned(dv))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv_varlen");
+  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, batch, H, max_seqlen_q, max_seqlen_k, scale, 0, g_dbg, 0};
+  fill_varlen_bwd(&p, cu_seqlens_q, cu_seqlens_k, H, total_q, D);
+  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv_varlen launch");
+  return 0;
 }
 
 }  // extern "C"

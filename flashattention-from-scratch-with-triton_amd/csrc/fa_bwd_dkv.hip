@@ -57,32 +57,40 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  // variable-length launch (fa_kernels.h VarLen): this sequence's rows and lengths; surplus workgroups exit
+  const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
+  const int Sq = si.Sq, Sk = si.Sk;
+  const int nk = (Sk + C::BK - 1) / C::BK;
+  if (idx >= (paired ? (nk + 1) / 2 : nk)) return;
+  const int npass = (paired && idx != nk - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int kt_idx = paired ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
+  const int kt_idx = paired ? (pass == 0 ? idx : nk - 1 - idx) : idx;  // low key tiles are the heavy ones
   const int k0_wg = kt_idx * C::BK;
   const int kw0 = k0_wg + wave * 32;
   if (pass) __syncthreads();  // the previous pass staged dK / dV in the tile buffers
 
-  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK, dV, LSE, delta are contiguous
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
-  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
-  const size_t koff = (size_t)bh * p.Sk * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq =
-      make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdo =
-      make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, (unsigned)(p.Sq - 1) * do_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk =
-      make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv =
-      make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
+  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK and dV carry their own layouts
+  // (contiguous for the reference's launch, packed rows for varlen); LSE / delta rows of one (batch, head) are contiguous
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs, dk_rs = p.ldk.rs, dv_rs = p.ldv.rs;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(
+      (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh + (long long)si.q0 * q_rs, (unsigned)(Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(
+      (const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh + (long long)si.q0 * do_rs, (unsigned)(Sq - 1) * do_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(
+      (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(
+      (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdk = make_rsrc(
+      (char*)p.dk + b_ * p.ldk.sb + h_ * p.ldk.sh + (long long)si.k0 * dk_rs, (unsigned)(Sk - 1) * dk_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdv = make_rsrc(
+      (char*)p.dv + b_ * p.ldv.sb + h_ * p.ldv.sh + (long long)si.k0 * dv_rs, (unsigned)(Sk - 1) * dv_rs + C::ROWB);
+  const long long rowc_off = b_ * p.lse_sb + h_ * p.lse_sh + si.q0;
   // Row constants of a query tile: wave 0 loads its LSE rows, wave 1 its delta rows, through ONE wave-uniform
   // descriptor and an unconditional load (a divergent `if` around the load makes hipcc wait vmcnt(0) at the merge,
   // which also waits for the tile DMA issued just before: the double buffer then hides nothing).
   const __amdgpu_buffer_rsrc_t rrc =
-      make_rsrc((wave == 0 ? p.lse : p.delta) + (size_t)bh * p.Sq, wave < 2 ? (unsigned)p.Sq * 4 : 0u);
+      make_rsrc((wave == 0 ? p.lse : p.delta) + rowc_off, wave < 2 ? (unsigned)Sq * 4 : 0u);
 
   const float c2 = p.scale * kLog2e;
   constexpr bool FOLD = T::kFoldScale;  // fa_common.h: the score chain starts from -LSE*log2e and K carries c2
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
     vf[ks] = as_vec8<T>(buf_load16(rv, off));
   }
 
-  const int ntiles = (p.Sq + C::BQ - 1) / C::BQ;
+  const int ntiles = (Sq + C::BQ - 1) / C::BQ;
   const int t_start = CAUSAL ? k0_wg / C::BQ : 0;
   // tiles t >= t_full are entirely below the diagonal for this wave's keys
   const int t_full = CAUSAL ? kw0 / C::BQ + 1 : 0;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     FA_LDS float* rc = (FA_LDS float*)(smem + C::ROWC_OFF + (t & 1) * C::ROWC_BYTES);
     // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
-    const float lse_c = (t * C::BQ + lane < p.Sq) ? -cst * kLog2e : -INFINITY;
+    const float lse_c = (t * C::BQ + lane < Sq) ? -cst * kLog2e : -INFINITY;
     if (wave < 2) rc[tid] = wave == 0 ? lse_c : -cst;  // rc[row] = -LSE*log2e, rc[64 + row] = -delta
   };
 
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
     }
   };
 
-  if (p.Sq % C::BQ != 0) {  // a ragged last query tile must not expose uninitialised LDS
+  if (Sq % C::BQ != 0) {  // a ragged last query tile must not expose uninitialised LDS
     lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
@@ -248,8 +256,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   }
 
   FA_LDS char* stage = smem + wave * 32 * C::ROWB;
-  store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * C::ROWB, lane);
-  store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * C::ROWB, lane);
+  store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
+  store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
   }  // pass
 }
 

@@ -75,29 +75,37 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
-
-  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK, dV, LSE, delta are contiguous
   const int b_ = bh / p.H, h_ = bh - b_ * p.H;
-  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
-  const size_t koff = (size_t)bh * p.Sk * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq =
-      make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdo =
-      make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, (unsigned)(p.Sq - 1) * do_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk =
-      make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv =
-      make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdk = make_rsrc((char*)p.dk + koff, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdv = make_rsrc((char*)p.dv + koff, (unsigned)p.Sk * C::ROWB);
+  // variable-length launch (fa_kernels.h VarLen): this sequence's rows and lengths; surplus workgroups exit
+  const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
+  const int Sq = si.Sq, Sk = si.Sk;
+  const int nk = (Sk + C::BK - 1) / C::BK;
+  if (idx >= (paired ? (nk + 1) / 2 : nk)) return;
+  const int npass = (paired && idx != nk - 1 - idx) ? 2 : 1;
+
+  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK and dV carry their own layouts
+  // (contiguous for the reference's launch, packed rows for varlen); LSE / delta rows of one (batch, head) are contiguous
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs, dk_rs = p.ldk.rs, dv_rs = p.ldv.rs;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(
+      (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh + (long long)si.q0 * q_rs, (unsigned)(Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(
+      (const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh + (long long)si.q0 * do_rs, (unsigned)(Sq - 1) * do_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(
+      (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(
+      (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdk = make_rsrc(
+      (char*)p.dk + b_ * p.ldk.sb + h_ * p.ldk.sh + (long long)si.k0 * dk_rs, (unsigned)(Sk - 1) * dk_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdv = make_rsrc(
+      (char*)p.dv + b_ * p.ldv.sb + h_ * p.ldv.sh + (long long)si.k0 * dv_rs, (unsigned)(Sk - 1) * dv_rs + C::ROWB);
+  const long long rowc_off = b_ * p.lse_sb + h_ * p.lse_sh + si.q0;
   // Row constants of a query tile: the first BQ/64 waves load its LSE rows, the next BQ/64 waves its delta rows,
   // through ONE wave-uniform descriptor and an unconditional load.  (A divergent `if` around the load makes
   // hipcc merge the loaded value with a copy, and the s_waitcnt vmcnt(0) it puts before that copy also waits for
   // the tile DMA issued just above it: the double buffer then hides nothing.)
   const bool rc_lse = wave < C::BQ / 64, rc_any = wave < 2 * C::BQ / 64;
   const __amdgpu_buffer_rsrc_t rrc =
-      make_rsrc((rc_lse ? p.lse : p.delta) + (size_t)bh * p.Sq, rc_any ? (unsigned)p.Sq * 4 : 0u);
+      make_rsrc((rc_lse ? p.lse : p.delta) + rowc_off, rc_any ? (unsigned)Sq * 4 : 0u);
   // row of the tile this thread serves; recomputed where it is used (volatile asm, one VALU op): as a loop
   // invariant hipcc spills it, and a scratch reload is a vmcnt wait just like the one this design avoids
   auto rc_row_now = [&]() __attribute__((always_inline)) -> int {
@@ -137,11 +145,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
   const float c2 = p.scale * kLog2e;
   constexpr bool FOLD = T::kFoldScale;  // fa_common.h: the score chain starts from -LSE*log2e and K carries c2
-  const int ntiles = (p.Sq + C::BQ - 1) / C::BQ;
+  const int ntiles = (Sq + C::BQ - 1) / C::BQ;
 
   // A ragged last query tile leaves its tail rows to an out-of-range DMA; make sure those LDS bytes
   // are finite (they are multiplied by P = 0).
-  if (p.Sq % C::BQ != 0) {
+  if (Sq % C::BQ != 0) {
     lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   unsigned long long last_ = 0, nblk_ = 0;
 #endif
   for (int pass = 0; pass < npass; ++pass) {
-    const int kt_idx = paired ? (pass == 0 ? idx : p.n_tiles - 1 - idx) : idx;  // low key tiles are the heavy ones
+    const int kt_idx = paired ? (pass == 0 ? idx : nk - 1 - idx) : idx;  // low key tiles are the heavy ones
     const int k0_wg = kt_idx * C::BK;
     const int kw0 = k0_wg + wave * 32;
     if (pass) __syncthreads();  // previous pass staged dK / dV in the tile buffers
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
       if (fetched) {
         FA_LDS float* rcp = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
         // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
-        const float lse_c = (t * C::BQ + rc_row_now() < p.Sq) ? -rc * kLog2e : -INFINITY;
+        const float lse_c = (t * C::BQ + rc_row_now() < Sq) ? -rc * kLog2e : -INFINITY;
         if (rc_any) rcp[tid] = rc_lse ? lse_c : -rc;  // rcp[row] = -LSE*log2e, rcp[BQ + row] = -delta
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the ds_write above
@@ -478,8 +486,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     if (t < ntiles) step_full(t, B0{});
 
     FA_LDS char* stage = smem + wave * 32 * C::ROWB;
-    store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * C::ROWB, lane);
-    store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * C::ROWB, lane);
+    store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
+    store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
   }  // pass
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {

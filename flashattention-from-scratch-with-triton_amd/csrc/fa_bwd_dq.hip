@@ -51,32 +51,39 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (paired && idx != p.n_tiles - 1 - idx) ? 2 : 1;
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  // variable-length launch (fa_kernels.h VarLen): this sequence's rows and lengths; surplus workgroups exit
+  const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
+  const int Sq = si.Sq, Sk = si.Sk;
+  const int nq = (Sq + C::BM - 1) / C::BM;
+  if (idx >= (paired ? (nq + 1) / 2 : nq)) return;
+  const int npass = (paired && idx != nq - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  // lane coordinates are re-derived per pass from an opaque thread id: as pass-invariant values hipcc keeps them (and
-  // the addresses computed from them) live across both passes and spills them at the 168-register budget
+  // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
   const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
-  const int qt = paired ? (pass == 0 ? p.n_tiles - 1 - idx : idx) : (CAUSAL ? p.n_tiles - 1 - idx : idx);  // heavy first
+  const int qt = paired ? (pass == 0 ? nq - 1 - idx : idx) : (CAUSAL ? nq - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 32;
   if (pass) __syncthreads();  // the previous pass staged its dQ tile in the K/V buffers
 
-  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); O, dQ, LSE, delta are contiguous
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
-  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
-  const size_t qoff = (size_t)bh * p.Sq * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq =
-      make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdo =
-      make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, (unsigned)(p.Sq - 1) * do_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)p.o + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + qoff, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk =
-      make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv =
-      make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
-  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); O and dQ carry their own layouts
+  // (contiguous for the reference's launch, packed rows for varlen); LSE / delta rows of one (batch, head) are contiguous
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs, o_rs = p.lo.rs, dq_rs = p.ldq.rs;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(
+      (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh + (long long)si.q0 * q_rs, (unsigned)(Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(
+      (const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh + (long long)si.q0 * do_rs, (unsigned)(Sq - 1) * do_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(
+      (const char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh + (long long)si.q0 * o_rs, (unsigned)(Sq - 1) * o_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rdq = make_rsrc(
+      (char*)p.dq + b_ * p.ldq.sb + h_ * p.ldq.sh + (long long)si.q0 * dq_rs, (unsigned)(Sq - 1) * dq_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(
+      (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(
+      (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const long long rowc_off = b_ * p.lse_sb + h_ * p.lse_sh + si.q0;
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + rowc_off, (unsigned)Sq * 4);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + rowc_off, (unsigned)Sq * 4);
 
   // ---- resident B operands: Q^T and dO^T of this wave's 32 rows; delta ----
   vec8 qf[C::KS], dof[C::KS];
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     const int col = (2 * ks + h) * 16;
     qf[ks] = as_vec8<T>(buf_load16(rq, (qw0 + r) * q_rs + col));
     dof[ks] = as_vec8<T>(buf_load16(rdo, (qw0 + r) * do_rs + col));
-    const vec8 of = as_vec8<T>(buf_load16(ro, (qw0 + r) * C::ROWB + col));
+    const vec8 of = as_vec8<T>(buf_load16(ro, (qw0 + r) * o_rs + col));
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum = __builtin_fmaf((float)dof[ks][j], (float)of[j], dsum);
   }
@@ -109,9 +116,9 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     for (int ks = 0; ks < C::KS; ++ks) qf[ks] = scale_frag<T>(qf[ks], c2);
   }
 
-  const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
+  const int kv_end = CAUSAL ? min(Sk, q0_wg + C::BM) : Sk;
   const int ntiles = (kv_end + C::BN - 1) / C::BN;
-  const int nfull = CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN;
+  const int nfull = CAUSAL ? min(Sk / C::BN, qw0 / C::BN) : Sk / C::BN;
 
   // LDS-DMA source offsets (see fa_fwd.hip): wave w fills rows [16w, 16w+16) of each tile
   constexpr int RPI = 1024 / C::ROWB;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       if constexpr (MASKED) {
-        bool use = s0 + 32 * b < p.Sk;
+        bool use = s0 + 32 * b < Sk;
         if (CAUSAL) use = use && (s0 + 32 * b <= qw0);
         if (!use) continue;
       }
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
         float x = FOLD ? sacc[i] : __builtin_fmaf(sacc[i], c2, nl);
         if constexpr (MASKED) {
           const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool dead = (CAUSAL && key > qw0 + r) || key >= p.Sk;
+          const bool dead = (CAUSAL && key > qw0 + r) || key >= Sk;
           x = dead ? -INFINITY : x;
         }
         sacc[i] = __builtin_amdgcn_exp2f(x) * pacc[i];  // dS^T = P^T o (dP^T - delta)
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     }
   };
 
-  if (p.Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS
+  if (Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS
     lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     tile_sync();
   }
 
-  store_tile_rows<D, T>(dqacc, p.scale, smem + wave * 32 * C::ROWB, rdq, qw0 * C::ROWB, lane);
+  store_tile_rows<D, T>(dqacc, p.scale, smem + wave * 32 * C::ROWB, rdq, qw0 * dq_rs, lane, dq_rs);
   }  // pass
 }
 

@@ -260,9 +260,11 @@ FA_DEVINL int xcd_remap(int b, int n) {
 // acc[db][i] holds OUT[row = lane & 31][col = db*32 + (i&3) + 8(i>>2) + 4h] * mul.
 // The wave stages its tile in its own LDS area (32 rows x D*2 bytes, swizzled) and
 // writes whole rows back with 16-byte stores (8 rows per 1-KiB wave instruction).
+// `row0_bytes` = byte offset of the tile's first row in `dst`, `ors` = byte stride between output rows (D*2 for the
+// reference's contiguous [B, H, S, D] outputs, H*D*2 for packed varlen rows).
 template <int D, typename T>
 FA_DEVINL void store_tile_rows(const f32x16 (&acc)[D / 32], float mul, FA_LDS char* stage,
-                               __amdgpu_buffer_rsrc_t dst, int row0_bytes, int lane) {
+                               __amdgpu_buffer_rsrc_t dst, int row0_bytes, int lane, int ors = D * 2) {
   // Opaque lane id: everything below is address arithmetic on `lane` that does not change from pass to pass, so hipcc
   // hoists it to kernel entry, keeps ~20 values live across the whole tile loop and, at the 168-register budget of
   // three workgroups per CU, spills them (22 dwords of scratch per lane in the headline dQ kernel).  Recomputing
@@ -287,7 +289,7 @@ FA_DEVINL void store_tile_rows(const f32x16 (&acc)[D / 32], float mul, FA_LDS ch
   for (int i = 0; i < (32 * CPR) / 64; ++i) {
     const int id = lane + 64 * i, row = id / CPR, c = id % CPR;
     u32x4 v = lds_read16(stage + lds_off<D>(row, c));
-    buf_store16(dst, row0_bytes + row * (D * 2) + c * 16, v);
+    buf_store16(dst, row0_bytes + row * ors + c * 16, v);
   }
 }
 

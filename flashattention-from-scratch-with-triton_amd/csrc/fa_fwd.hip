@@ -73,28 +73,35 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
   const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  // variable-length launch: this sequence's rows and lengths come from cu_seqlens; the grid was sized for the longest
+  // sequence, so workgroups past this one's own tile count have nothing to do
+  const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
+  const int Sq = si.Sq, Sk = si.Sk;
+  const int nq = (Sq + C::BM - 1) / C::BM;
+  if (idx >= (paired ? (nq + 1) / 2 : nq)) return;
+  const int npass = (paired && idx != nq - 1 - idx) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
   const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
-  const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
+  const int qt = paired ? (pass == 0 ? nq - 1 - idx : idx) : (CAUSAL ? nq - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
   const int qw0 = q0_wg + wave * 32;
   if (pass) __syncthreads();  // the previous pass staged its O tile in the K/V buffers
 
   // inputs may be strided views with a contiguous head dim (e.g. a [B,S,H,D] buffer seen as [B,H,S,D]): per-tensor
-  // batch / head byte strides, one row stride for Q and one shared by K and V; O and LSE are contiguous
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
-  const int q_rs = p.lq.rs, kv_rs = p.lk.rs;
-  const char* qb = (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh;
-  const char* kb = (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh;
-  const char* vb = (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh;
-  char* ob = (char*)p.o + (size_t)bh * p.Sq * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  // batch / head byte strides, one row stride for Q and one shared by K and V; O has its own layout (contiguous for the
+  // reference's launch, packed rows for varlen), LSE rows of one (batch, head) are contiguous
+  const int q_rs = p.lq.rs, kv_rs = p.lk.rs, o_rs = p.lo.rs;
+  const char* qb = (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh + (long long)si.q0 * q_rs;
+  const char* kb = (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh + (long long)si.k0 * kv_rs;
+  const char* vb = (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs;
+  char* ob = (char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh + (long long)si.q0 * o_rs;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)(Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)(Sq - 1) * o_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + b_ * p.lse_sb + h_ * p.lse_sh + si.q0, (unsigned)Sq * 4);
 
   // ---- Q^T fragments (B operand), resident for the whole kernel ----
   vec8 qf[C::KS];
@@ -103,10 +110,10 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
     qf[ks] = as_vec8<T>(buf_load16(rq, (qw0 + r) * q_rs + (2 * ks + h) * 16));
 
   // ---- tile schedule ----
-  const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
+  const int kv_end = CAUSAL ? min(Sk, q0_wg + C::BM) : Sk;
   const int ntiles = (kv_end + C::BN - 1) / C::BN;
   // tiles [0, nfull) need no mask for this wave
-  const int nfull = CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN;
+  const int nfull = CAUSAL ? min(Sk / C::BN, qw0 / C::BN) : Sk / C::BN;
 
   // ---- staging addresses ----
   // ---- LDS-DMA: wave w fills rows [16w, 16w+16) of each K / V tile, 1 KiB (1024 / ROWB rows) per instruction;
@@ -196,8 +203,8 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
         use[0] = s0 <= qw0;        // key block start <= first row of the wave
         use[1] = s0 + 32 <= qw0;
       }
-      use[0] = use[0] && s0 < p.Sk;
-      use[1] = use[1] && s0 + 32 < p.Sk;
+      use[0] = use[0] && s0 < Sk;
+      use[1] = use[1] && s0 + 32 < Sk;
       if (!use[0] && !use[1]) return;
     }
     f32x16 sacc[2];
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool dead = (CAUSAL && key > qrow) || key >= p.Sk;
+          const bool dead = (CAUSAL && key > qrow) || key >= Sk;
           sacc[b][i] = dead ? -INFINITY : sacc[b][i];
         }
       }
@@ -298,8 +305,8 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
         use[0] = s0 <= qw0;
         use[1] = s0 + 32 <= qw0;
       }
-      use[0] = use[0] && s0 < p.Sk;
-      use[1] = use[1] && s0 + 32 < p.Sk;
+      use[0] = use[0] && s0 < Sk;
+      use[1] = use[1] && s0 + 32 < Sk;
       if (!use[0] && !use[1]) return true;  // nothing of this tile is visible to the wave
     }
     f32x16 sacc[2];
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
         float x = FOLD ? sacc[b][i] : __builtin_fmaf(sacc[b][i], c2, -mc);
         if constexpr (MASKED) {
           const int key = s0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool dead = (CAUSAL && key > qw0 + r) || key >= p.Sk;
+          const bool dead = (CAUSAL && key > qw0 + r) || key >= Sk;
           x = dead ? -INFINITY : x;
         }
         const float pe = __builtin_amdgcn_exp2f(x);
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
   using BR = std::integral_constant<int, -1>;
 
   // ---- main loop: one barrier per tile; every wave runs exactly ntiles iterations ----
-  if (p.Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS (out-of-range DMA may not write)
+  if (Sk % C::BN != 0) {  // a ragged last tile must not expose uninitialised LDS (out-of-range DMA may not write)
     lds_zero_fill(smem, C::LDS_BYTES, C::NT, tid);
     __syncthreads();
   }
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
   const float lt = half_sum(l);
   const float inv = 1.0f / lt;
   // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
-  store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * C::ROWB, lane);
+  store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * o_rs, lane, o_rs);
   if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
   }  // pass
 }

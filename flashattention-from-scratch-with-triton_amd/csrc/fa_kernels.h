@@ -19,19 +19,45 @@ inline TensorLayout contiguous_layout(int H, int S, int D) {
   return TensorLayout{(long long)H * S * D * 2, (long long)S * D * 2, D * 2};
 }
 
+// Variable-length ("varlen") launches: Q/K/V/O and the gradients are PACKED [total tokens, H, D] tensors, sequence b
+// owns rows [cu[b], cu[b+1]) (cu_seqlens_q / cu_seqlens_k, int32, batch + 1 entries, device memory); LSE and delta are
+// [H, total_q].  The kernels then take S_q / S_k and every base pointer per (batch, head) from the cu arrays; the grid
+// is sized for the longest sequence and workgroups beyond a sequence's own tile count exit at once.  cu_q == nullptr:
+// the fixed-length [B, H, S, D] launch of the reference.
+struct VarLen {
+  const int* cu_q;
+  const int* cu_k;
+};
+
+// A sequence's first packed row and its lengths (varlen), or {0, 0, S_q, S_k} for the fixed-length launch.  `b` is
+// workgroup-uniform, so these are four scalar loads.
+struct SeqInfo {
+  int q0, k0, Sq, Sk;
+};
+__device__ __forceinline__ SeqInfo seq_info(const VarLen& vl, int b, int Sq, int Sk) {
+  if (!vl.cu_q) return SeqInfo{0, 0, Sq, Sk};
+  const int q0 = vl.cu_q[b], q1 = vl.cu_q[b + 1], k0 = vl.cu_k[b], k1 = vl.cu_k[b + 1];
+  return SeqInfo{q0, k0, q1 - q0, k1 - k0};
+}
+
 struct FwdParams {
   const void* q;
   const void* k;
   const void* v;
   void* o;
   float* lse;
-  int B, H, Sq, Sk;
+  int B, H, Sq, Sk;  // varlen: Sq / Sk = the LONGEST sequence (grid sizing); the kernel reads the real ones
   float scale;
   int nq_tiles;  // filled by the launcher
   void* dbg;     // diagnostic builds (-DFA_STAMPS) only: cycle-stamp buffer, else unused
   int pair;      // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
   TensorLayout lq, lk, lv;  // K and V share their row stride (checked by the C ABI)
-  bool all_contiguous(int D) const { return lq.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D); }
+  TensorLayout lo;          // output O: contiguous [B, H, S, D] for the reference's launch, packed rows for varlen
+  long long lse_sb, lse_sh; // LSE element strides per batch / head (rows of one (batch, head) are contiguous)
+  VarLen vl;
+  bool all_contiguous(int D) const {
+    return !vl.cu_q && lq.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
+  }
 };
 
 struct BwdParams {
@@ -50,9 +76,12 @@ struct BwdParams {
   int n_tiles;      // filled by the launcher
   void* dbg;        // diagnostic builds (-DFA_STAMPS) only
   int pair;         // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
-  TensorLayout lq, lk, lv, ldo;  // K and V share their row stride (checked by the C ABI); O is contiguous
+  TensorLayout lq, lk, lv, ldo;  // K and V share their row stride (checked by the C ABI)
+  TensorLayout lo, ldq, ldk, ldv;  // O (input of the dQ kernel) and the gradient outputs: contiguous, or packed rows (varlen)
+  long long lse_sb, lse_sh;        // LSE / delta element strides per batch / head
+  VarLen vl;
   bool all_contiguous(int D) const {
-    return lq.contiguous(H, Sq, D) && ldo.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
+    return !vl.cu_q && lq.contiguous(H, Sq, D) && ldo.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
   }
 };
 

@@ -186,6 +186,96 @@ Tensor flash_attention(const Tensor& Q, const Tensor& K, const Tensor& V, bool i
   return FlashAttnFn::apply(Q, K, V, is_causal);
 }
 
+// ---- variable-length sequences: packed [total, H, D] tensors + cu_seqlens (include/mi355fa.h, fa_*_varlen) ---------
+void check_varlen(const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& cu_q, const Tensor& cu_k) {
+  FA_ASSERT(Q.dim() == 3 && K.dim() == 3 && V.dim() == 3, "varlen Q, K, V must be packed [total tokens, H, D]");
+  FA_ASSERT(Q.is_cuda() && K.is_cuda() && V.is_cuda() && cu_q.is_cuda() && cu_k.is_cuda(), "varlen tensors must be device tensors");
+  FA_ASSERT(K.sizes() == V.sizes(), "K and V must have the same shape");
+  FA_ASSERT(Q.size(1) == K.size(1) && Q.size(2) == K.size(2), "Q, K, V must share heads and head dim");
+  FA_ASSERT(Q.scalar_type() == K.scalar_type() && Q.scalar_type() == V.scalar_type(), "Q, K, V must share their dtype");
+  FA_ASSERT(Q.device() == K.device() && Q.device() == V.device() && Q.device() == cu_q.device() && Q.device() == cu_k.device(),
+            "all varlen tensors must be on the same device");
+  FA_ASSERT(cu_q.scalar_type() == at::kInt && cu_k.scalar_type() == at::kInt && cu_q.dim() == 1 && cu_k.dim() == 1 &&
+                cu_q.is_contiguous() && cu_k.is_contiguous() && cu_q.numel() == cu_k.numel() && cu_q.numel() >= 2,
+            "cu_seqlens_q / cu_seqlens_k must be contiguous int32 vectors of batch + 1 entries");
+  FA_ASSERT(Q.size(2) == 64 || Q.size(2) == 128, "head dim must be 64 or 128");
+}
+Tensor packed(const Tensor& t) {  // the varlen kernels read packed rows only: copy anything else
+  return (t.is_contiguous() && reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0) ? t : t.clone(at::MemoryFormat::Contiguous);
+}
+
+std::tuple<Tensor, Tensor> varlen_forward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, const Tensor& cu_q,
+                                                 const Tensor& cu_k, int64_t max_q, int64_t max_k, bool causal) {
+  check_varlen(Q_, K_, V_, cu_q, cu_k);
+  Tensor Q = packed(Q_), K = packed(K_), V = packed(V_);
+  const int64_t Tq = Q.size(0), Tk = K.size(0), H = Q.size(1), D = Q.size(2), B = cu_q.numel() - 1;
+  c10::OptionalDeviceGuard guard(Q.device());
+  Tensor O = torch::empty({Tq, H, D}, Q.options());
+  Tensor LSE = torch::empty({H, Tq}, Q.options().dtype(at::kFloat));
+  check_rc(fa_fwd_varlen(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), (float*)LSE.data_ptr(),
+                         (const int*)cu_q.data_ptr(), (const int*)cu_k.data_ptr(), (int)B, (int)H, (int)Tq, (int)Tk, (int)max_q,
+                         (int)max_k, (int)D, dtype_code(Q), causal ? 1 : 0, (float)(1.0 / std::sqrt((double)D)),
+                         current_stream(Q)),
+           "fa_fwd_varlen");
+  return {O, LSE};
+}
+
+std::tuple<Tensor, Tensor, Tensor> varlen_backward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, const Tensor& O_,
+                                                          const Tensor& dO_, const Tensor& LSE, const Tensor& cu_q,
+                                                          const Tensor& cu_k, int64_t max_q, int64_t max_k, bool causal) {
+  check_varlen(Q_, K_, V_, cu_q, cu_k);
+  FA_ASSERT(O_.sizes() == Q_.sizes() && dO_.sizes() == Q_.sizes(), "O and dO must have Q's shape");
+  FA_ASSERT(LSE.dim() == 2 && LSE.size(0) == Q_.size(1) && LSE.size(1) == Q_.size(0) && LSE.scalar_type() == at::kFloat &&
+                LSE.is_contiguous() && LSE.device() == Q_.device(),
+            "LSE must be contiguous float32 [H, total_q]");
+  Tensor Q = packed(Q_), K = packed(K_), V = packed(V_), O = packed(O_), dO = packed(dO_);
+  const int64_t Tq = Q.size(0), Tk = K.size(0), H = Q.size(1), D = Q.size(2), B = cu_q.numel() - 1;
+  c10::OptionalDeviceGuard guard(Q.device());
+  Tensor dQ = torch::empty({Tq, H, D}, Q.options());
+  Tensor g = torch::empty({2, Tk, H, D}, Q.options());
+  Tensor dK = g.select(0, 0), dV = g.select(0, 1);
+  Tensor delta = torch::empty({H, Tq}, Q.options().dtype(at::kFloat));
+  void* st = current_stream(Q);
+  const float scale = (float)(1.0 / std::sqrt((double)D));
+  const int dt = dtype_code(Q);
+  check_rc(fa_bwd_dq_varlen(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                            dQ.data_ptr(), (float*)delta.data_ptr(), (const int*)cu_q.data_ptr(), (const int*)cu_k.data_ptr(),
+                            (int)B, (int)H, (int)Tq, (int)Tk, (int)max_q, (int)max_k, (int)D, dt, causal ? 1 : 0, scale, st),
+           "fa_bwd_dq_varlen");
+  check_rc(fa_bwd_dkv_varlen(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                             (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (const int*)cu_q.data_ptr(),
+                             (const int*)cu_k.data_ptr(), (int)B, (int)H, (int)Tq, (int)Tk, (int)max_q, (int)max_k, (int)D, dt,
+                             causal ? 1 : 0, scale, st),
+           "fa_bwd_dkv_varlen");
+  return {dQ, dK, dV};
+}
+
+class FlashAttnVarlenFn : public torch::autograd::Function<FlashAttnVarlenFn> {
+ public:
+  static Tensor forward(AutogradContext* ctx, const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& cu_q,
+                        const Tensor& cu_k, int64_t max_q, int64_t max_k, bool is_causal) {
+    FA_ASSERT(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kBFloat16, "dtype must be float16 or bfloat16");
+    Tensor Q_ = packed(Q), K_ = packed(K), V_ = packed(V);
+    auto out = varlen_forward_launch(Q_, K_, V_, cu_q, cu_k, max_q, max_k, is_causal);
+    ctx->save_for_backward({Q_, K_, V_, std::get<0>(out), std::get<1>(out), cu_q, cu_k});
+    ctx->saved_data["is_causal"] = is_causal;
+    ctx->saved_data["max_q"] = max_q;
+    ctx->saved_data["max_k"] = max_k;
+    return std::get<0>(out);
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grads) {
+    auto s = ctx->get_saved_variables();
+    auto g = varlen_backward_launch(s[0], s[1], s[2], s[3], grads[0], s[4], s[5], s[6], ctx->saved_data["max_q"].toInt(),
+                                    ctx->saved_data["max_k"].toInt(), ctx->saved_data["is_causal"].toBool());
+    return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor flash_attention_varlen(const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& cu_q, const Tensor& cu_k,
+                              int64_t max_q, int64_t max_k, bool is_causal) {
+  return FlashAttnVarlenFn::apply(Q, K, V, cu_q, cu_k, max_q, max_k, is_causal);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_mi355fa_torch, m) {
@@ -194,5 +284,10 @@ PYBIND11_MODULE(_mi355fa_torch, m) {
         pybind11::arg("is_causal") = false);
   m.def("forward_launch", &forward_launch);
   m.def("backward_launch", &backward_launch);
+  m.def("flash_attention_varlen", &flash_attention_varlen, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
+        pybind11::arg("cu_seqlens_q"), pybind11::arg("cu_seqlens_k"), pybind11::arg("max_seqlen_q"),
+        pybind11::arg("max_seqlen_k"), pybind11::arg("is_causal") = false);
+  m.def("varlen_forward_launch", &varlen_forward_launch);
+  m.def("varlen_backward_launch", &varlen_backward_launch);
   m.def("abi_version", []() { return fa_abi_version(); });
 }

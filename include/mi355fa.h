@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355FA_ABI_VERSION 2
+#define MI355FA_ABI_VERSION 3
 
 /* dtype codes */
 #define MI355FA_FP16 0
@@ -101,6 +101,27 @@ int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k,
                        const void* v, const long long* v_strides, const void* dout, const long long* dout_strides,
                        const float* lse, const float* delta, void* dk, void* dv,
                        int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
+
+/* ---- Variable-length sequences (the extension the reference names as an exercise,
+ * Phase_6.md:119-178: "concatenate the sequences of a batch into one long sequence and record where each one starts").
+ *
+ * Layout ("thd", packed): q, o, dout, dq : [total_q, H, D];  k, v, dk, dv : [total_k, H, D];  lse, delta : [H, total_q]
+ * (fp32).  Sequence b owns the rows [cu_seqlens_q[b], cu_seqlens_q[b+1]) of the q-side tensors and
+ * [cu_seqlens_k[b], cu_seqlens_k[b+1]) of the k-side ones; cu_seqlens_* are DEVICE int32 arrays of batch + 1 entries
+ * starting at 0 (prefix sums of the lengths; a length of 0 is allowed).  max_seqlen_* (host values, >= the longest
+ * sequence) size the launch grid.  Attention is computed inside each sequence only; causal != 0 applies each sequence's
+ * own top-left aligned mask.  Everything else (ownership, stream, return codes, dQ before dK/dV) is as above. */
+int fa_fwd_varlen(const void* q, const void* k, const void* v, void* o, float* lse, const int* cu_seqlens_q,
+                  const int* cu_seqlens_k, int batch, int H, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k,
+                  int D, int dtype, int causal, float scale, void* stream);
+int fa_bwd_dq_varlen(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                     float* delta, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
+                     int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
+                     void* stream);
+int fa_bwd_dkv_varlen(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                      void* dk, void* dv, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
+                      int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
+                      void* stream);
 
 #ifdef __cplusplus
 }

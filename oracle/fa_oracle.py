@@ -273,3 +273,29 @@ def cpu_sdpa(Q, K, V, is_causal, dO=None):
     o = F.scaled_dot_product_attention(q, k, v, is_causal=is_causal)
     o.backward(dO)
     return o.detach(), q.grad, k.grad, v.grad
+
+
+def attention_varlen_fp64(Q, K, V, dO, cu_q, cu_k, causal):
+    """Ground truth for the variable-length extension (reference text Phase_6.md:119-178; not implemented in the
+    reference): packed Q [total_q, H, D], K / V [total_k, H, D], dO like Q; cu_q / cu_k = prefix sums (lists or int
+    tensors).  Every sequence is an independent attention_fp64 problem.  Returns packed O, dQ, dK, dV (fp64), LSE and
+    delta as [H, total_q]."""
+    cu_q = [int(x) for x in cu_q]
+    cu_k = [int(x) for x in cu_k]
+    Tq, H, D = Q.shape
+    out = {"O": torch.zeros(Q.shape, dtype=torch.float64), "dQ": torch.zeros(Q.shape, dtype=torch.float64),
+           "dK": torch.zeros(K.shape, dtype=torch.float64), "dV": torch.zeros(V.shape, dtype=torch.float64),
+           "LSE": torch.zeros(H, Tq, dtype=torch.float64), "delta": torch.zeros(H, Tq, dtype=torch.float64)}
+    for b in range(len(cu_q) - 1):
+        q0, q1, k0, k1 = cu_q[b], cu_q[b + 1], cu_k[b], cu_k[b + 1]
+        if q1 == q0 or k1 == k0:
+            continue
+        sl = lambda t, a, e: t[a:e].transpose(0, 1).unsqueeze(0)      # [1, H, S, D]
+        g = attention_fp64(sl(Q, q0, q1), sl(K, k0, k1), sl(V, k0, k1), sl(dO, q0, q1), causal)
+        out["O"][q0:q1] = g["O"][0].transpose(0, 1)
+        out["dQ"][q0:q1] = g["dQ"][0].transpose(0, 1)
+        out["dK"][k0:k1] = g["dK"][0].transpose(0, 1)
+        out["dV"][k0:k1] = g["dV"][0].transpose(0, 1)
+        out["LSE"][:, q0:q1] = g["LSE"][0]
+        out["delta"][:, q0:q1] = g["delta"][0]
+    return out

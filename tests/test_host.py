@@ -20,8 +20,9 @@ def _header_functions():
 
 
 def test_header_declares_expected_entry_points():
-    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_strided", "fa_bwd_dq", "fa_bwd_dq_strided",
-                                   "fa_fwd", "fa_fwd_strided", "fa_last_error", "fa_supported"]
+    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_strided", "fa_bwd_dkv_varlen", "fa_bwd_dq",
+                                   "fa_bwd_dq_strided", "fa_bwd_dq_varlen", "fa_fwd", "fa_fwd_strided", "fa_fwd_varlen",
+                                   "fa_last_error", "fa_supported"]
 
 
 def test_library_exports_every_declared_symbol():
@@ -30,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(raw, name), name
         assert name in fa.SIGNATURES, "python binding misses " + name
-    assert fa.lib.fa_abi_version() == 2
+    assert fa.lib.fa_abi_version() == 3
     assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
@@ -38,8 +39,9 @@ def test_library_exports_every_declared_symbol():
 def test_torch_binding_loads_and_matches_the_abi():
     import _mi355fa as fa
     import _mi355fa_torch as ext
-    assert ext.abi_version() == fa.ABI_VERSION == 2
-    for name in ("flash_attention", "forward_launch", "backward_launch"):
+    assert ext.abi_version() == fa.ABI_VERSION == 3
+    for name in ("flash_attention", "forward_launch", "backward_launch", "flash_attention_varlen", "varlen_forward_launch",
+                 "varlen_backward_launch"):
         assert callable(getattr(ext, name)), name
     q = torch.randn(1, 1, 8, 64, dtype=torch.float16)
     with pytest.raises(AssertionError, match="device tensors"):       # M:133, before any allocation or launch
@@ -102,6 +104,28 @@ def test_schedule_table_lookup_and_override():
         force(0, 0, 0)
     hdr = open(os.path.join(PKG, "csrc", "fa_table.h")).read()
     assert hdr.startswith("// GENERATED by tools/tune.py") and "kFamily[3][2][2][2]" in hdr
+
+
+def test_varlen_argument_errors_are_rejected_before_launch():
+    import _mi355fa as fa
+    import My_FlashAttention_optimized as M
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    L = fa.lib
+    tail = (2, 4, 100, 100, 64, 64, 64, 1, 0, 0.125, None)   # batch, H, total_q, total_k, max_q, max_k, D, dtype, causal, scale, stream
+    assert L.fa_fwd_varlen(p, p, p, p, p, None, p, *tail) == -1 and b"cu_seqlens" in L.fa_last_error()
+    assert L.fa_fwd_varlen(None, p, p, p, p, p, p, *tail) == -1
+    assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 100, 100, 200, 64, 64, 1, 0, 0.125, None) == -2    # max_q > total_q
+    assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 100, 100, 64, 64, 96, 1, 0, 0.125, None) == -3     # head dim
+    assert L.fa_bwd_dq_varlen(p, p, p, p, p, p, p, p, p, p + 4, 2, 4, 100, 100, 64, 64, 64, 7, 0, 0.125, None) == -4
+    assert L.fa_bwd_dkv_varlen(p, p, p, p, p, p, p, p + 2, p, p, *tail) == -5
+    q = torch.randn(10, 2, 64, dtype=torch.float16)
+    cu = torch.tensor([0, 4, 10], dtype=torch.int32)
+    with pytest.raises(AssertionError, match="device tensors"):
+        M.flash_attention_varlen(q, q, q, cu, cu, 6, 6, True)
+    sig = [(p_.name, p_.default) for p_ in inspect.signature(M.flash_attention_varlen).parameters.values()]
+    assert [n for n, _ in sig] == ["Q", "K", "V", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "is_causal"]
+    assert sig[-1][1] is False
 
 
 def test_strided_ok_accepts_bshd_views_and_rejects_the_rest():

@@ -93,3 +93,28 @@ def test_flops_kat():
             assert fo.attention_flops(c["B"], c["H"], c["S"], c["S"], c["D"], c["causal"], mode) == c[mode]
     assert fo.attention_flops(4, 32, 4096, 4096, 64, True, "fwd") == 274_877_906_944
     assert fo.attention_flops(4, 32, 4096, 4096, 64, True, "fwd_bwd") == 962_072_674_304
+
+
+def test_varlen_oracle_equals_the_batched_oracle_on_equal_lengths():
+    """attention_varlen_fp64 (the ground truth of the varlen extension, Phase_6.md:119-178) on a batch whose sequences
+    all have the same length is the batched fp64 oracle on the packed-to-[B,H,S,D] view, and sequences do not leak."""
+    torch.manual_seed(3)
+    B, H, S, D = 3, 2, 24, 16
+    Q, K, V, dO = (torch.randn(B, H, S, D) for _ in range(4))
+    pack = lambda t: t.transpose(1, 2).reshape(B * S, H, D)
+    cu = [0, S, 2 * S, 3 * S]
+    for causal in (False, True):
+        ref = fo.attention_fp64(Q, K, V, dO, causal)
+        got = fo.attention_varlen_fp64(pack(Q), pack(K), pack(V), pack(dO), cu, cu, causal)
+        for k in ("O", "dQ", "dK", "dV"):
+            assert torch.allclose(got[k], pack(ref[k]), atol=1e-12), k
+        assert torch.allclose(got["LSE"], ref["LSE"].permute(1, 0, 2).reshape(H, B * S), atol=1e-12)
+    # ragged, different q / k lengths, one empty sequence: each sequence is its own problem
+    cu_q, cu_k = [0, 5, 5, 17], [0, 9, 12, 20]
+    Q, dO = torch.randn(17, H, D), torch.randn(17, H, D)
+    K, V = torch.randn(20, H, D), torch.randn(20, H, D)
+    got = fo.attention_varlen_fp64(Q, K, V, dO, cu_q, cu_k, True)
+    one = fo.attention_fp64(Q[5:17].transpose(0, 1)[None], K[12:20].transpose(0, 1)[None], V[12:20].transpose(0, 1)[None],
+                            dO[5:17].transpose(0, 1)[None], True)
+    assert torch.allclose(got["O"][5:17], one["O"][0].transpose(0, 1), atol=1e-12)
+    assert got["dK"][9:12].abs().max() == 0          # keys of the empty-query sequence get no gradient
