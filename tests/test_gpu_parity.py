@@ -393,12 +393,22 @@ def test_strided_views_are_read_in_place_and_bit_identical(D, causal, dtype, imp
     # autograd level: gradients flow back to the fused buffer; no .contiguous() copy of the views is saved
     x = qkv.clone().requires_grad_(True)
     q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
-    o = M.flash_attention(q, k, v, causal)
+    o = M.FlashAttentionFunction.apply(q, k, v, causal)              # the Python class exposes what it saved
     saved = o.grad_fn.saved_tensors
     assert saved[0].data_ptr() == q.data_ptr() and saved[1].data_ptr() == k.data_ptr()   # views, not copies
     o.backward(dOv)
     ref = torch.stack([g.transpose(1, 2) for g in g1], dim=2)                # [B, S, 3, H, D]
     assert torch.equal(x.grad, ref)
+    # the C++ autograd function behind flash_attention(): same gradients, and no 3 x |Q| of copies either
+    x2 = qkv.clone().requires_grad_(True)
+    q2, k2, v2 = (x2[:, :, i].transpose(1, 2) for i in range(3))
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    o2 = M.flash_attention(q2, k2, v2, causal)
+    grown = torch.cuda.memory_allocated() - before
+    assert grown < 1.5 * (o2.numel() * o2.element_size() + 4 * B * H * Sq) + (1 << 20), grown   # O + LSE only
+    o2.backward(dOv)
+    assert torch.equal(x2.grad, ref)
     # and against the fp64 oracle, like every other case
     gt = fo.attention_fp64(Qv.cpu(), Kv.cpu(), Vv.cpu(), dOv.cpu(), causal)
     tol = 1e-3 if dtype == F16 else 5e-3
@@ -474,8 +484,13 @@ def test_expanded_kv_heads_are_read_in_place(dtype):
     dO = torch.randn(B, H, S, D, device="cuda", dtype=dtype)
     k, v = k1.expand(B, H, S, D), v1.expand(B, H, S, D)
     assert k.stride(1) == 0 and fa.strided_ok(k) and fa.strided_ok(v)
-    o = M.flash_attention(q, k, v, True)
-    assert o.grad_fn.saved_tensors[1].data_ptr() == k1.data_ptr()          # the expanded view, not a copy
+    op = M.FlashAttentionFunction.apply(q, k, v, True)                      # the Python class exposes what it saved
+    assert op.grad_fn.saved_tensors[1].data_ptr() == k1.data_ptr()         # the expanded view, not a copy
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    o = M.flash_attention(q, k, v, True)                                   # C++ autograd function: no K/V copy either
+    assert torch.cuda.memory_allocated() - before < 1.5 * (o.numel() * o.element_size() + 4 * B * H * S) + (1 << 20)
+    assert torch.equal(o, op)
     o.backward(dO)
     q2 = q.detach().clone().requires_grad_(True)
     k2 = k.detach().contiguous().requires_grad_(True)
