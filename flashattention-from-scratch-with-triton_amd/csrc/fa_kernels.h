@@ -130,7 +130,11 @@ inline int pick_dkv_impl(int forced, int D, int dtype, int B, int H, int Sq, int
 // Causal tile pairing equalises the work per workgroup but halves the number of workgroups: worth it as
 // long as the paired grid still gives every one of the 256 CUs a workgroup (measured: B4 H8 S2048 -> 256
 // pairs: 0.030 ms paired vs 0.038 ms unpaired; S512 -> 64 pairs: 0.014 vs 0.010 ms).
+#ifndef FA_NO_PAIRS
 inline int want_pairs(bool causal, long tiles, long bh) { return causal && ((tiles + 1) / 2) * bh >= 256; }
+#else   // A/B hook: heavy-first single tiles instead of pairs
+inline int want_pairs(bool, long, long) { return 0; }
+#endif
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s);
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s);
