@@ -115,6 +115,18 @@ def flash_attention_varlen(Q, K, V, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
                                        bool(is_causal))
 
 
+def flash_attention_dropout(Q, K, V, is_causal=False, dropout_p=0.0, seed=0, offset=0):
+    """Attention with dropout on the attention weights -- the other extension the reference leaves as an exercise
+    (Phase_6.md:54-113): P is masked and rescaled by 1 / (1 - p) inside the tile loop, and the backward regenerates the
+    SAME mask from (seed, offset) with Philox4x32-10 instead of storing it (include/mi355fa.h, fa_*_dropout, gives the
+    exact counter layout).  Q, K, V: [B, H, S, D] fp16 / bf16 device tensors; dropout_p in [0, 1), quantised to 1/256;
+    seed / offset: Python ints (the caller owns the RNG stream: pass a fresh offset per layer and step).  Differentiable
+    w.r.t. Q, K, V.  dropout_p = 0 is flash_attention."""
+    if dropout_p == 0.0:
+        return flash_attention(Q, K, V, is_causal)
+    return _ext.flash_attention_dropout(Q, K, V, bool(is_causal), float(dropout_p), int(seed), int(offset))
+
+
 def sdpa_reference(Q, K, V, is_causal):
     """torch SDPA on the device, fp16/bf16 (the reference pins the FLASH backend, M:178;
     here whatever backend this PyTorch-ROCm build selects)."""

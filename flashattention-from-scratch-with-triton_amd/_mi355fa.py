@@ -10,10 +10,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355fa.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FP16, BF16 = 0, 1
 
-_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_vp, _i, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ulonglong
 _sp = ctypes.POINTER(ctypes.c_longlong)   # const long long* strides (3 element strides) or NULL
 
 # name -> (restype, argtypes); mirrors include/mi355fa.h one to one
@@ -33,6 +33,11 @@ SIGNATURES = {
     "fa_fwd_varlen": (_i, [_vp] * 5 + [_vp] * 2 + [_i] * 9 + [_f, _vp]),
     "fa_bwd_dq_varlen": (_i, [_vp] * 8 + [_vp] * 2 + [_i] * 9 + [_f, _vp]),
     "fa_bwd_dkv_varlen": (_i, [_vp] * 8 + [_vp] * 2 + [_i] * 9 + [_f, _vp]),
+    # attention dropout: the fixed-length signatures + p_drop (float), seed, offset (unsigned long long), stream
+    "fa_dropout_keep_scale": (_f, [_f]),
+    "fa_fwd_dropout": (_i, [_vp] * 5 + [_i] * 7 + [_f, _f, _u64, _u64, _vp]),
+    "fa_bwd_dq_dropout": (_i, [_vp] * 8 + [_i] * 7 + [_f, _f, _u64, _u64, _vp]),
+    "fa_bwd_dkv_dropout": (_i, [_vp] * 8 + [_i] * 7 + [_f, _f, _u64, _u64, _vp]),
 }
 
 

@@ -256,4 +256,78 @@ int fa_bwd_dkv_varlen(const void* q, const void* k, const void* v, const void* d
   return 0;
 }
 
+// ---- attention dropout (include/mi355fa.h, fa_*_dropout): contiguous [B, H, S, D] tensors as fa_fwd / fa_bwd_* ----
+static int make_dropout(const char* fn, float p_drop, unsigned long long seed, unsigned long long offset,
+                        fa::DropoutParams* out) {
+  if (!(p_drop >= 0.f) || p_drop >= 1.f) return fail(MI355FA_ERR_SHAPE, "%s: dropout probability must be in [0, 1)", fn);
+  unsigned thresh = (unsigned)(p_drop * 256.f + 0.5f);   // p is quantised to multiples of 1/256
+  if (thresh > 255u) thresh = 255u;
+  out->thresh = thresh;
+  out->seed_lo = (unsigned)seed;
+  out->seed_hi = (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32);
+  out->offset = (unsigned)offset;
+  out->rp = 256.f / (256.f - (float)thresh);
+  return 0;
+}
+
+float fa_dropout_keep_scale(float p_drop) {   // 1 / (1 - p) for the quantised p the kernels use
+  fa::DropoutParams d;
+  if (make_dropout("fa_dropout_keep_scale", p_drop, 0, 0, &d)) return 0.f;
+  return d.rp;
+}
+
+int fa_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+                   int dtype, int causal, float scale, float p_drop, unsigned long long seed, unsigned long long offset,
+                   void* stream) {
+  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd_dropout");
+  if (int rc = check_common("fa_fwd_dropout", B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd_dropout");
+  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  p.lq = p.lo = fa::contiguous_layout(H, S_q, D);
+  p.lk = p.lv = fa::contiguous_layout(H, S_k, D);
+  p.lse_sb = (long long)H * S_q;
+  p.lse_sh = S_q;
+  if (int rc = make_dropout("fa_fwd_dropout", p_drop, seed, offset, &p.drop)) return rc;
+  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_fwd_dropout launch");
+  return 0;
+}
+
+int fa_bwd_dq_dropout(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                      float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, float p_drop,
+                      unsigned long long seed, unsigned long long offset, void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq_dropout");
+  if (int rc = check_common("fa_bwd_dq_dropout", B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
+      misaligned(dq) || misaligned(delta))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq_dropout");
+  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  p.lq = p.ldo = fa::contiguous_layout(H, S_q, D);
+  p.lk = p.lv = fa::contiguous_layout(H, S_k, D);
+  set_contiguous_outputs(&p, H, S_q, S_k, D);
+  if (int rc = make_dropout("fa_bwd_dq_dropout", p_drop, seed, offset, &p.drop)) return rc;
+  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq_dropout launch");
+  return 0;
+}
+
+int fa_bwd_dkv_dropout(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                       void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+                       float p_drop, unsigned long long seed, unsigned long long offset, void* stream) {
+  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv_dropout");
+  if (int rc = check_common("fa_bwd_dkv_dropout", B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
+      misaligned(dk) || misaligned(dv))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv_dropout");
+  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  p.lq = p.ldo = fa::contiguous_layout(H, S_q, D);
+  p.lk = p.lv = fa::contiguous_layout(H, S_k, D);
+  set_contiguous_outputs(&p, H, S_q, S_k, D);
+  if (int rc = make_dropout("fa_bwd_dkv_dropout", p_drop, seed, offset, &p.drop)) return rc;
+  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv_dropout launch");
+  return 0;
+}
+
 }  // extern "C"

@@ -39,7 +39,9 @@ struct DkvCfg {
   static constexpr int LDS_BYTES = 4 * TILE_BYTES + 2 * ROWC_BYTES;
 };
 
-template <int D, typename T, bool CAUSAL>
+// DROP: attention dropout (fa_common.h `Dropout`): dV uses the masked, rescaled P; dP = mask / (1 - p) o (dO V^T), so the
+// dP chain starts from zero and -delta is added per element.
+template <int D, typename T, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdParams p) {
   using C = DkvCfg<D>;
   using vec8 = typename T::vec8;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       const FA_LDS char* dbp = dt + b * 32 * C::ROWB;
       // per-register row constants: reg i <-> row (i&3) + 8(i>>2) + 4h
       // both MFMA chains START from them: with K pre-scaled the first delivers s*c2 - LSE*log2e, the second dP - delta
-      f32x16 nl, pacc, sacc;
+      f32x16 nl, nd, pacc, sacc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 a = *(const FA_LDS f32x4*)(rc + (32 * b + 8 * g + 4 * h) * 4);
@@ -185,8 +187,9 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           nl[4 * g + j] = a[j];
+          nd[4 * g + j] = d[j];
           sacc[4 * g + j] = FOLD ? a[j] : 0.f;
-          pacc[4 * g + j] = d[j];
+          pacc[4 * g + j] = DROP ? 0.f : d[j];
         }
       }
 #pragma unroll
@@ -208,7 +211,24 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
         }
         const float pe = __builtin_amdgcn_exp2f(x);
         sacc[i] = pe;             // P
-        pacc[i] = pe * pacc[i];   // dS = P o (dP - delta)
+        if constexpr (!DROP) pacc[i] = pe * pacc[i];   // dS = P o (dP - delta)
+      }
+      if constexpr (DROP) {
+        const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+        const int key = kw0 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 patch = dropout_patch(dr, (qb0 + 8 * g + 4 * h) >> 2, key >> 2, bh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {   // register 4g + j <-> query 4*qg + j: word j of the patch, byte key & 3
+            const int i = 4 * g + j;
+            const bool keep = ((patch[j] >> (8 * (key & 3))) & 255u) >= dr.thresh;
+            const float pe = sacc[i];
+            const float dp = keep ? pacc[i] * dr.rp : 0.f;     // dP = mask / (1 - p) o (dO V^T)
+            pacc[i] = pe * (dp + nd[i]);                       // dS = P o (dP - delta)
+            sacc[i] = keep ? pe * dr.rp : 0.f;                 // dropped, rescaled P for dV
+          }
+        }
       }
       const vec8 p0 = pack8<T, 0>(sacc), p1 = pack8<T, 1>(sacc);
       const vec8 s0 = pack8<T, 0>(pacc), s1 = pack8<T, 1>(pacc);
@@ -261,11 +281,11 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   }  // pass
 }
 
-template <int D, typename T, bool CAUSAL>
+template <int D, typename T, bool CAUSAL, bool DROP = false>
 static hipError_t launch(const BwdParams& p, hipStream_t s) {
   using C = DkvCfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
-  auto kern = fa_bwd_dkv_kernel<D, T, CAUSAL>;
+  auto kern = fa_bwd_dkv_kernel<D, T, CAUSAL, DROP>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
     static bool opted_in = false;    // (per template instance; a racing second call only repeats an idempotent setting)
     if (!opted_in) {
@@ -281,11 +301,13 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 hipError_t launch_bwd_dkv_v2(BwdParams p, int D, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v2.hip
 
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  const int impl = pick_dkv_impl(g_force_dkv, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0);
+  const int impl = p.drop.thresh ? 1 : pick_dkv_impl(g_force_dkv, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0);
   if (impl == 2) return launch_bwd_dkv_v2(p, D, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
-#define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
+#define FA_GO(DD, TT)                                                                           \
+  (p.drop.thresh ? (causal ? launch<DD, TT, true, true>(p, s) : launch<DD, TT, false, true>(p, s)) \
+                 : (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s)))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
 #undef FA_GO

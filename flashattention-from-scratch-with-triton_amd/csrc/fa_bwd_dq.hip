@@ -36,7 +36,9 @@ struct DqCfg {
 };
 
 // OCC = workgroups per CU the register allocation is held to (2: 256 VGPRs, 3: 168).
-template <int D, typename T, bool CAUSAL, int OCC>
+// DROP: attention dropout (fa_common.h `Dropout`): dP = mask / (1 - p) o (dO V^T), so the dP chain starts from zero and
+// the mask, the rescale and -delta are applied per element before dS = P o (dP - delta).
+template <int D, typename T, bool CAUSAL, int OCC, bool DROP = false>
 __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   using C = DqCfg<D>;
   using vec8 = typename T::vec8;
@@ -187,6 +189,10 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
       const FA_LDS char* kbp = kt + b * 32 * C::ROWB;
       const FA_LDS char* vbp = vt + b * 32 * C::ROWB;
       f32x16 sacc = nlse, pacc = ndelta;
+      if constexpr (DROP) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(kbp + row_off[ks]));
@@ -205,7 +211,24 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
           const bool dead = (CAUSAL && key > qw0 + r) || key >= Sk;
           x = dead ? -INFINITY : x;
         }
-        sacc[i] = __builtin_amdgcn_exp2f(x) * pacc[i];  // dS^T = P^T o (dP^T - delta)
+        if constexpr (!DROP) sacc[i] = __builtin_amdgcn_exp2f(x) * pacc[i];  // dS^T = P^T o (dP^T - delta)
+        else sacc[i] = __builtin_amdgcn_exp2f(x);                             // P^T; the mask comes next
+      }
+      if constexpr (DROP) {
+        const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+        const int qrow = qw0 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 patch = dropout_patch(dr, qrow >> 2, (s0 + 32 * b + 8 * g + 4 * h) >> 2, bh);
+          const unsigned w = select_word(patch, qrow & 3);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * g + j;
+            const bool keep = ((w >> (8 * j)) & 255u) >= dr.thresh;
+            const float dp = keep ? pacc[i] * dr.rp : 0.f;   // dP = mask / (1 - p) o (dO V^T)
+            sacc[i] = sacc[i] * (dp - delta);                // dS = P o (dP - delta)
+          }
+        }
       }
       const vec8 d0 = pack8<T, 0>(sacc);
       const vec8 d1 = pack8<T, 1>(sacc);
@@ -241,17 +264,17 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   }  // pass
 }
 
-template <int D, typename T, bool CAUSAL, int OCC = 2>
+template <int D, typename T, bool CAUSAL, int OCC = 2, bool DROP = false>
 static hipError_t launch(const BwdParams& p, hipStream_t s) {
   using C = DqCfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   // Three workgroups per CU pay off for the bf16 kernel (no fma/sub in its hot loop, fa_common.h kFoldScale) once
   // the grid fills them: +3 % causal, +7 % non-causal at B4 H32 N4096.  The tighter register budget spills in
   // the prologue only, which costs small grids more than the occupancy gives (B4 H8 S1024: -16 %); fp16: no gain.
-  if constexpr (OCC == 2 && D == 64 && T::kFoldScale) {
+  if constexpr (OCC == 2 && D == 64 && T::kFoldScale && !DROP) {
     if (grid >= 3 * 256) return launch<D, T, CAUSAL, 3>(p, s);
   }
-  auto kern = fa_bwd_dq_kernel<D, T, CAUSAL, OCC>;
+  auto kern = fa_bwd_dq_kernel<D, T, CAUSAL, OCC, DROP>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
     static bool opted_in = false;    // (per template instance; a racing second call only repeats an idempotent setting)
     if (!opted_in) {
@@ -268,12 +291,14 @@ hipError_t launch_bwd_dq_v2(BwdParams p, int dtype, int causal, hipStream_t s); 
 hipError_t launch_bwd_dq_v3(BwdParams p, int dtype, int causal, hipStream_t s);  // fa_bwd_dq_v3.hip
 
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  const int impl = pick_dq_impl(g_force_dq, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.all_contiguous(D));
+  const int impl = p.drop.thresh ? 1 : pick_dq_impl(g_force_dq, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.all_contiguous(D));
   if (impl == 3) return launch_bwd_dq_v3(p, dtype, causal, s);
   if (impl == 2) return launch_bwd_dq_v2(p, dtype, causal, s);
   p.n_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
-#define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
+#define FA_GO(DD, TT)                                                                                 \
+  (p.drop.thresh ? (causal ? launch<DD, TT, true, 2, true>(p, s) : launch<DD, TT, false, 2, true>(p, s)) \
+                 : (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s)))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
 #undef FA_GO

@@ -247,6 +247,48 @@ FA_DEVINL float half_sum(float v) {
   return a + b;
 }
 
+// ---- attention dropout (reference text Phase_6.md:54-113: "Philox lets forward and backward regenerate
+// the same mask from (seed, offset) without storing it") --------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; the generator PyTorch / cuRAND / hipRAND use): counter-based, so the keep
+// decision of attention weight (b, h, q, k) is a pure function of its coordinates and (seed, offset) -- the three kernels
+// regenerate identical masks although they tile and orient the score matrix differently.
+// One call yields 16 random bytes = the 4 x 4 patch of weights  q in [4*qg, 4*qg+4) x k in [4*kg, 4*kg+4):
+// byte (k & 3) of word (q & 3).  A weight is KEPT iff its byte >= thresh (thresh = round(256 p), p quantised to 1/256)
+// and kept weights are scaled by rp = 256 / (256 - thresh).  In every kernel a lane's 16 accumulator registers of a
+// 32 x 32 block are four 1 x 4 (forward, dQ: lane = query) or 4 x 1 (dK/dV: lane = key) strips of four different
+// patches: four Philox calls per block and lane.  v_mul_hi / v_mul_lo are quarter rate on CDNA4: the dropout kernels
+// are several times slower than the plain ones, which are separate template instances and pay nothing.
+struct Dropout {
+  unsigned thresh;            // 0 = no dropout (the plain kernels are launched)
+  unsigned seed_lo, seed_hi;  // Philox key
+  unsigned offset;            // fourth counter word (the caller's Philox offset)
+  float rp;                   // 1 / (1 - thresh / 256)
+};
+FA_DEVINL u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+  constexpr unsigned kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const unsigned hi0 = __umulhi(kM0, c0), lo0 = kM0 * c0;
+    const unsigned hi1 = __umulhi(kM1, c2), lo1 = kM1 * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = lo1;
+    c2 = n2;
+    c3 = lo0;
+    k0 += kW0;
+    k1 += kW1;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+// the 4 x 4 patch of random bytes holding weights (4*qg.., 4*kg..) of (batch*head) slice `bh`
+FA_DEVINL u32x4 dropout_patch(const Dropout& d, int qg, int kg, int bh) {
+  return philox4x32_10((unsigned)qg, (unsigned)kg, (unsigned)bh, d.offset, d.seed_lo, d.seed_hi);
+}
+FA_DEVINL unsigned select_word(const u32x4& w, int idx) {  // idx in 0..3, lane dependent
+  const unsigned lo = (idx & 1) ? w[1] : w[0], hi = (idx & 1) ? w[3] : w[2];
+  return (idx & 2) ? hi : lo;
+}
+
 // ---- workgroup -> work item, XCD aware ------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
 // Give every XCD one contiguous slice of the work list so that the q/k tiles of one

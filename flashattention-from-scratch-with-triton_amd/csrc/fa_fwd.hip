@@ -55,8 +55,10 @@ constexpr float kDeferLog2 = 6.0f;
 // Lazy running max: largest partial row sum accepted without recomputing the true max (see tile_lazy).
 constexpr float kLazySumMax = 8192.0f;
 
-template <int D, typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel(FwdParams p) {
+// DROP: attention dropout (fa_common.h `Dropout`): P is masked and rescaled before P @ V, l keeps summing the
+// undropped p (the softmax normalisation is not affected by dropout); every tile takes the exact path.
+template <int D, typename T, bool CAUSAL, bool DROP = false>
+__global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_fwd_kernel(FwdParams p) {
   using C = FwdCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -268,6 +270,24 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
         ls[i & 3] += pe;
       }
     l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    if constexpr (DROP) {  // keep / drop each weight; kept ones are scaled by 1 / (1 - p)
+      const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+      const int qrow = qw0 + r;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (MASKED && !use[b]) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 patch = dropout_patch(dr, qrow >> 2, (s0 + 32 * b + 8 * g + 4 * h) >> 2, bh);
+          const unsigned w = select_word(patch, qrow & 3);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool keep = ((w >> (8 * j)) & 255u) >= dr.thresh;
+            sacc[b][4 * g + j] = keep ? sacc[b][4 * g + j] * dr.rp : 0.f;
+          }
+        }
+      }
+    }
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -382,6 +402,18 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
   // merge control flow get their accumulators copied at every join.
   int t = 0;
   bool prefetched = false;
+  if constexpr (DROP) {  // the lazy path commits P before the mask could be applied consistently: exact tiles only
+    for (; t < nfull; ++t) {
+      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
+      tile(t, BR{}, std::false_type{});
+      tile_sync();
+    }
+    for (; t < ntiles; ++t) {
+      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
+      tile(t, BR{}, std::true_type{});
+      tile_sync();
+    }
+  }
   while (t < nfull) {
     if (!prefetched && t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
     tile(t, BR{}, std::false_type{});
@@ -415,11 +447,11 @@ __global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel
 }
 
 // ---- host launcher ----------------------------------------------------------
-template <int D, typename T, bool CAUSAL>
+template <int D, typename T, bool CAUSAL, bool DROP = false>
 static hipError_t launch(const FwdParams& p, hipStream_t s) {
   using C = FwdCfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
-  auto kern = fa_fwd_kernel<D, T, CAUSAL>;
+  auto kern = fa_fwd_kernel<D, T, CAUSAL, DROP>;
   if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
     static bool opted_in = false;    // (per template instance; a racing second call only repeats an idempotent setting)
     if (!opted_in) {
@@ -435,11 +467,13 @@ static hipError_t launch(const FwdParams& p, hipStream_t s) {
 hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v2.hip
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  if (pick_fwd_impl(g_force_fwd, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.all_contiguous(D)) == 2)
+  if (!p.drop.thresh && pick_fwd_impl(g_force_fwd, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.all_contiguous(D)) == 2)
     return launch_fwd_v2(p, dtype, causal, s);
   p.nq_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.nq_tiles, (long)p.B * p.H);
-#define FA_GO(DD, TT) (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s))
+#define FA_GO(DD, TT)                                                                           \
+  (p.drop.thresh ? (causal ? launch<DD, TT, true, true>(p, s) : launch<DD, TT, false, true>(p, s)) \
+                 : (causal ? launch<DD, TT, true>(p, s) : launch<DD, TT, false>(p, s)))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
 #undef FA_GO

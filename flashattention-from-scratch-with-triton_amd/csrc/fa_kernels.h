@@ -29,6 +29,13 @@ struct VarLen {
   const int* cu_k;
 };
 
+// Attention dropout parameters as the kernels see them (fa_common.h `Dropout` has the same members; kept separate so
+// that host code does not need the device header).  thresh == 0: no dropout.
+struct DropoutParams {
+  unsigned thresh, seed_lo, seed_hi, offset;
+  float rp;
+};
+
 // A sequence's first packed row and its lengths (varlen), or {0, 0, S_q, S_k} for the fixed-length launch.  `b` is
 // workgroup-uniform, so these are four scalar loads.
 struct SeqInfo {
@@ -55,6 +62,7 @@ struct FwdParams {
   TensorLayout lo;          // output O: contiguous [B, H, S, D] for the reference's launch, packed rows for varlen
   long long lse_sb, lse_sh; // LSE element strides per batch / head (rows of one (batch, head) are contiguous)
   VarLen vl;
+  DropoutParams drop;
   bool all_contiguous(int D) const {
     return !vl.cu_q && lq.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
   }
@@ -80,6 +88,7 @@ struct BwdParams {
   TensorLayout lo, ldq, ldk, ldv;  // O (input of the dQ kernel) and the gradient outputs: contiguous, or packed rows (varlen)
   long long lse_sb, lse_sh;        // LSE / delta element strides per batch / head
   VarLen vl;
+  DropoutParams drop;
   bool all_contiguous(int D) const {
     return !vl.cu_q && lq.contiguous(H, Sq, D) && ldo.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
   }
@@ -110,6 +119,7 @@ inline int table_family(int kernel, int D, int dtype, bool causal, long bh, long
   return table::kFamily[kernel][D == 128][dtype == 1][causal ? 1 : 0][nearest_log2_bucket(bh, table::kBH, table::kNumBH)]
                        [nearest_log2_bucket(S, table::kS, table::kNumS)];
 }
+// (launches with dropout always take family 1: the dropout variants exist for that family only)
 inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
   int f = forced ? forced : table_family(kKernelFwd, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
   if (f == 2 && (D != 64 || !contiguous)) f = 1;

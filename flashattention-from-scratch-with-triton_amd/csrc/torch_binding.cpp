@@ -276,6 +276,86 @@ Tensor flash_attention_varlen(const Tensor& Q, const Tensor& K, const Tensor& V,
   return FlashAttnVarlenFn::apply(Q, K, V, cu_q, cu_k, max_q, max_k, is_causal);
 }
 
+// ---- attention dropout (include/mi355fa.h, fa_*_dropout): contiguous [B, H, S, D] tensors --------------------------
+Tensor dense(const Tensor& t) {
+  return (t.is_contiguous() && reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0) ? t : t.clone(at::MemoryFormat::Contiguous);
+}
+
+std::tuple<Tensor, Tensor> dropout_forward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, bool causal, double p_drop,
+                                                  int64_t seed, int64_t offset) {
+  check_qkv(Q_, K_, V_);
+  FA_ASSERT(Q_.is_cuda(), "Q, K, V must be device tensors");
+  FA_ASSERT(p_drop >= 0.0 && p_drop < 1.0, "dropout_p must be in [0, 1)");
+  Tensor Q = dense(Q_), K = dense(K_), V = dense(V_);
+  const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
+  c10::OptionalDeviceGuard guard(Q.device());
+  Tensor O = torch::empty({B, H, Sq, D}, Q.options());
+  Tensor LSE = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
+  check_rc(fa_fwd_dropout(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), (float*)LSE.data_ptr(), (int)B, (int)H, (int)Sq,
+                          (int)Sk, (int)D, dtype_code(Q), causal ? 1 : 0, (float)(1.0 / std::sqrt((double)D)), (float)p_drop,
+                          (unsigned long long)seed, (unsigned long long)offset, current_stream(Q)),
+           "fa_fwd_dropout");
+  return {O, LSE};
+}
+
+std::tuple<Tensor, Tensor, Tensor> dropout_backward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, const Tensor& O_,
+                                                           const Tensor& dO_, const Tensor& LSE, bool causal, double p_drop,
+                                                           int64_t seed, int64_t offset) {
+  check_qkv(Q_, K_, V_);
+  FA_ASSERT(Q_.is_cuda(), "Q, K, V must be device tensors");
+  FA_ASSERT(O_.sizes() == Q_.sizes() && dO_.sizes() == Q_.sizes(), "O and dO must have Q's shape");
+  FA_ASSERT(LSE.dim() == 3 && LSE.scalar_type() == at::kFloat && LSE.is_contiguous() && LSE.device() == Q_.device(),
+            "LSE must be contiguous float32 [B, H, S_q]");
+  Tensor Q = dense(Q_), K = dense(K_), V = dense(V_), O = dense(O_), dO = dense(dO_);
+  const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
+  c10::OptionalDeviceGuard guard(Q.device());
+  Tensor dQ = torch::empty({B, H, Sq, D}, Q.options());
+  Tensor g = torch::empty({2, B, H, Sk, D}, Q.options());
+  Tensor dK = g.select(0, 0), dV = g.select(0, 1);
+  Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
+  void* st = current_stream(Q);
+  const float scale = (float)(1.0 / std::sqrt((double)D));
+  const int dt = dtype_code(Q);
+  check_rc(fa_bwd_dq_dropout(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                             dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
+                             scale, (float)p_drop, (unsigned long long)seed, (unsigned long long)offset, st),
+           "fa_bwd_dq_dropout");
+  check_rc(fa_bwd_dkv_dropout(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                              (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D,
+                              dt, causal ? 1 : 0, scale, (float)p_drop, (unsigned long long)seed, (unsigned long long)offset, st),
+           "fa_bwd_dkv_dropout");
+  return {dQ, dK, dV};
+}
+
+class FlashAttnDropoutFn : public torch::autograd::Function<FlashAttnDropoutFn> {
+ public:
+  static Tensor forward(AutogradContext* ctx, const Tensor& Q, const Tensor& K, const Tensor& V, bool is_causal, double p_drop,
+                        int64_t seed, int64_t offset) {
+    FA_ASSERT(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kBFloat16, "dtype must be float16 or bfloat16");
+    FA_ASSERT(Q.dim() == 4 && (Q.size(3) == 64 || Q.size(3) == 128), "head dim must be 64 or 128");
+    Tensor Q_ = dense(Q), K_ = dense(K), V_ = dense(V);
+    auto out = dropout_forward_launch(Q_, K_, V_, is_causal, p_drop, seed, offset);
+    ctx->save_for_backward({Q_, K_, V_, std::get<0>(out), std::get<1>(out)});
+    ctx->saved_data["is_causal"] = is_causal;
+    ctx->saved_data["p"] = p_drop;
+    ctx->saved_data["seed"] = seed;
+    ctx->saved_data["offset"] = offset;
+    return std::get<0>(out);
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grads) {
+    auto s = ctx->get_saved_variables();
+    auto g = dropout_backward_launch(s[0], s[1], s[2], s[3], grads[0], s[4], ctx->saved_data["is_causal"].toBool(),
+                                     ctx->saved_data["p"].toDouble(), ctx->saved_data["seed"].toInt(),
+                                     ctx->saved_data["offset"].toInt());
+    return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor flash_attention_dropout(const Tensor& Q, const Tensor& K, const Tensor& V, bool is_causal, double p_drop, int64_t seed,
+                               int64_t offset) {
+  return FlashAttnDropoutFn::apply(Q, K, V, is_causal, p_drop, seed, offset);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_mi355fa_torch, m) {
@@ -289,5 +369,10 @@ PYBIND11_MODULE(_mi355fa_torch, m) {
         pybind11::arg("max_seqlen_k"), pybind11::arg("is_causal") = false);
   m.def("varlen_forward_launch", &varlen_forward_launch);
   m.def("varlen_backward_launch", &varlen_backward_launch);
+  m.def("flash_attention_dropout", &flash_attention_dropout, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
+        pybind11::arg("is_causal"), pybind11::arg("dropout_p"), pybind11::arg("seed"), pybind11::arg("offset") = 0);
+  m.def("dropout_forward_launch", &dropout_forward_launch);
+  m.def("dropout_backward_launch", &dropout_backward_launch);
+  m.def("dropout_keep_scale", [](double p) { return (double)fa_dropout_keep_scale((float)p); });
   m.def("abi_version", []() { return fa_abi_version(); });
 }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355FA_ABI_VERSION 3
+#define MI355FA_ABI_VERSION 4
 
 /* dtype codes */
 #define MI355FA_FP16 0
@@ -122,6 +122,27 @@ int fa_bwd_dkv_varlen(const void* q, const void* k, const void* v, const void* d
                       void* dk, void* dv, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
                       int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
                       void* stream);
+
+/* ---- Attention dropout (the other extension the reference names as an exercise,
+ * Phase_6.md:54-113: "a reproducible, indexable RNG -- Philox -- so that forward and backward use the same mask").
+ *
+ * Same tensors and contract as fa_fwd / fa_bwd_dq / fa_bwd_dkv (contiguous [B, H, S, D]).  Each attention weight
+ * P[b, h, q, k] is kept with probability 1 - p and scaled by 1 / (1 - p), else set to 0; LSE is that of the undropped
+ * softmax.  The keep decision is a pure function of (b*H + h, q, k, seed, offset): Philox4x32-10 with key =
+ * {seed[31:0], seed[63:32] ^ offset[63:32]} and counter = {q >> 2, k >> 2, b*H + h, offset[31:0]} yields the 16 bytes of the
+ * 4 x 4 patch around (q, k) -- byte (k & 3) of output word (q & 3) -- and the weight is kept iff its byte >= round(256 p)
+ * (p is quantised to multiples of 1/256; fa_dropout_keep_scale(p) returns the exact 1 / (1 - p) in use).  The three
+ * kernels must be given the same (p_drop, seed, offset).  p_drop = 0 runs the plain kernels. */
+float fa_dropout_keep_scale(float p_drop);
+int fa_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+                   int dtype, int causal, float scale, float p_drop, unsigned long long seed, unsigned long long offset,
+                   void* stream);
+int fa_bwd_dq_dropout(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                      float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, float p_drop,
+                      unsigned long long seed, unsigned long long offset, void* stream);
+int fa_bwd_dkv_dropout(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                       void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+                       float p_drop, unsigned long long seed, unsigned long long offset, void* stream);
 
 #ifdef __cplusplus
 }

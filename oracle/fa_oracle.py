@@ -299,3 +299,61 @@ def attention_varlen_fp64(Q, K, V, dO, cu_q, cu_k, causal):
         out["LSE"][:, q0:q1] = g["LSE"][0]
         out["delta"][:, q0:q1] = g["delta"][0]
     return out
+
+
+# --------------------------------------------------------------------------
+# attention dropout (reference text Phase_6.md:54-113; not implemented in the reference)
+# --------------------------------------------------------------------------
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) on numpy uint32 arrays (broadcast): returns the 4 output words.
+    Pinned by the Random123 known-answer vectors in tests/test_oracle.py."""
+    import numpy as np
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint32) for x in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0.astype(np.uint64)
+        p1 = M1 * c2.astype(np.uint64)
+        hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint32(k0), lo1, hi0 ^ c3 ^ np.uint32(k1), lo0
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def dropout_keep_mask(B, H, Sq, Sk, p_drop, seed, offset=0):
+    """The keep mask the kernels regenerate (include/mi355fa.h, fa_*_dropout): bool [B, H, Sq, Sk] and the scale
+    1 / (1 - p) of the quantised p.  Weight (b, h, q, k): byte (k & 3) of word (q & 3) of
+    Philox(counter = {q >> 2, k >> 2, b*H + h, offset[31:0]}, key = {seed[31:0], seed[63:32] ^ offset[63:32]}) >= round(256 p)."""
+    import numpy as np
+    thresh = min(255, int(p_drop * 256.0 + 0.5))
+    k0 = seed & 0xFFFFFFFF
+    k1 = ((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFF
+    qg = np.arange((Sq + 3) // 4, dtype=np.uint32)[None, :, None]
+    kg = np.arange((Sk + 3) // 4, dtype=np.uint32)[None, None, :]
+    bh = np.arange(B * H, dtype=np.uint32)[:, None, None]
+    words = philox4x32_10(qg, kg, bh, np.uint32(offset & 0xFFFFFFFF), k0, k1)          # 4 x [BH, Sq/4, Sk/4]
+    w = np.stack(words, axis=2)                                                       # [BH, Sq/4, 4 (q&3), Sk/4]
+    byts = np.stack([(w >> np.uint32(8 * j)) & np.uint32(255) for j in range(4)], axis=-1)   # [..., Sk/4, 4 (k&3)]
+    keep = (byts >= thresh).reshape(B * H, 4 * qg.shape[1], 4 * kg.shape[2])[:, :Sq, :Sk]
+    return torch.from_numpy(keep.reshape(B, H, Sq, Sk).copy()), 256.0 / (256.0 - thresh)
+
+
+def attention_dropout_fp64(Q, K, V, dO, is_causal, keep, rp):
+    """fp64 attention with the given keep mask on the softmax weights: O = (keep * rp * softmax(S)) V; autograd grads.
+    LSE is that of the undropped softmax; delta = rowsum(dO * O)."""
+    q = Q.detach().to(torch.float64).requires_grad_(True)
+    k = K.detach().to(torch.float64).requires_grad_(True)
+    v = V.detach().to(torch.float64).requires_grad_(True)
+    D = q.shape[-1]
+    S = q @ k.transpose(-2, -1) * (1.0 / math.sqrt(D))
+    if is_causal:
+        Sq, Sk = S.shape[-2:]
+        S = S.masked_fill(~(torch.arange(Sq)[:, None] >= torch.arange(Sk)[None, :]), float("-inf"))
+    lse = torch.logsumexp(S, dim=-1)
+    P = torch.exp(S - lse[..., None]) * keep.to(torch.float64) * rp
+    O = P @ v
+    do = dO.detach().to(torch.float64)
+    O.backward(do)
+    return {"O": O.detach(), "LSE": lse.detach(), "dQ": q.grad, "dK": k.grad, "dV": v.grad,
+            "delta": (do * O.detach()).sum(-1)}

@@ -20,9 +20,10 @@ def _header_functions():
 
 
 def test_header_declares_expected_entry_points():
-    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_strided", "fa_bwd_dkv_varlen", "fa_bwd_dq",
-                                   "fa_bwd_dq_strided", "fa_bwd_dq_varlen", "fa_fwd", "fa_fwd_strided", "fa_fwd_varlen",
-                                   "fa_last_error", "fa_supported"]
+    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_dropout", "fa_bwd_dkv_strided",
+                                   "fa_bwd_dkv_varlen", "fa_bwd_dq", "fa_bwd_dq_dropout", "fa_bwd_dq_strided",
+                                   "fa_bwd_dq_varlen", "fa_dropout_keep_scale", "fa_fwd", "fa_fwd_dropout", "fa_fwd_strided",
+                                   "fa_fwd_varlen", "fa_last_error", "fa_supported"]
 
 
 def test_library_exports_every_declared_symbol():
@@ -31,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(raw, name), name
         assert name in fa.SIGNATURES, "python binding misses " + name
-    assert fa.lib.fa_abi_version() == 3
+    assert fa.lib.fa_abi_version() == 4
     assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
@@ -39,9 +40,9 @@ def test_library_exports_every_declared_symbol():
 def test_torch_binding_loads_and_matches_the_abi():
     import _mi355fa as fa
     import _mi355fa_torch as ext
-    assert ext.abi_version() == fa.ABI_VERSION == 3
+    assert ext.abi_version() == fa.ABI_VERSION == 4
     for name in ("flash_attention", "forward_launch", "backward_launch", "flash_attention_varlen", "varlen_forward_launch",
-                 "varlen_backward_launch"):
+                 "varlen_backward_launch", "flash_attention_dropout", "dropout_forward_launch", "dropout_backward_launch"):
         assert callable(getattr(ext, name)), name
     q = torch.randn(1, 1, 8, 64, dtype=torch.float16)
     with pytest.raises(AssertionError, match="device tensors"):       # M:133, before any allocation or launch
@@ -104,6 +105,27 @@ def test_schedule_table_lookup_and_override():
         force(0, 0, 0)
     hdr = open(os.path.join(PKG, "csrc", "fa_table.h")).read()
     assert hdr.startswith("// GENERATED by tools/tune.py") and "kFamily[3][2][2][2]" in hdr
+
+
+def test_dropout_arguments_and_keep_scale():
+    import _mi355fa as fa
+    import My_FlashAttention_optimized as M
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    L = fa.lib
+    assert L.fa_fwd_dropout(p, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, 1.0, 1, 0, None) == -2 and b"[0, 1)" in L.fa_last_error()
+    assert L.fa_fwd_dropout(p, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, -0.1, 1, 0, None) == -2
+    assert L.fa_fwd_dropout(None, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, 0.1, 1, 0, None) == -1
+    assert L.fa_bwd_dq_dropout(p, p, p, p, p, p, p, p, 1, 1, 8, 8, 96, 1, 0, 0.125, 0.1, 1, 0, None) == -3
+    assert L.fa_bwd_dkv_dropout(p, p, p, p, p, p, p, p + 2, 1, 1, 8, 8, 64, 1, 0, 0.125, 0.1, 1, 0, None) == -5
+    assert abs(L.fa_dropout_keep_scale(0.25) - 256.0 / 192.0) < 1e-6 and L.fa_dropout_keep_scale(0.0) == 1.0
+    assert abs(L.fa_dropout_keep_scale(0.1) - 256.0 / (256 - 26)) < 1e-6        # p quantised to 26 / 256
+    q = torch.randn(1, 1, 8, 64, dtype=torch.float16)
+    with pytest.raises(AssertionError, match="device tensors"):
+        M.flash_attention_dropout(q, q, q, True, 0.1, seed=3)
+    sig = [(p_.name, p_.default) for p_ in inspect.signature(M.flash_attention_dropout).parameters.values()]
+    assert sig == [("Q", inspect.Parameter.empty), ("K", inspect.Parameter.empty), ("V", inspect.Parameter.empty),
+                   ("is_causal", False), ("dropout_p", 0.0), ("seed", 0), ("offset", 0)]
 
 
 def test_varlen_argument_errors_are_rejected_before_launch():

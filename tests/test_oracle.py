@@ -118,3 +118,27 @@ def test_varlen_oracle_equals_the_batched_oracle_on_equal_lengths():
                             dO[5:17].transpose(0, 1)[None], True)
     assert torch.allclose(got["O"][5:17], one["O"][0].transpose(0, 1), atol=1e-12)
     assert got["dK"][9:12].abs().max() == 0          # keys of the empty-query sequence get no gradient
+
+
+def test_philox4x32_10_known_answers_and_keep_mask_layout():
+    """The oracle's Philox against the Random123 known-answer vectors (kat_vectors: philox4x32 10), and the byte /
+    word layout of the 4 x 4 keep patches the kernels regenerate (include/mi355fa.h, fa_*_dropout)."""
+    import numpy as np
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kats:
+        got = fo.philox4x32_10(*[np.uint32(c) for c in ctr], key[0], key[1])
+        assert tuple(int(x) for x in got) == out
+    keep, rp = fo.dropout_keep_mask(2, 3, 37, 50, 0.25, seed=0x123456789abcdef, offset=7)
+    assert keep.shape == (2, 3, 37, 50) and rp == 256.0 / 192.0
+    # element (b=1, h=2, q=13, k=22): word q & 3 = 1, byte k & 3 = 2 of the patch (q >> 2, k >> 2) = (3, 5)
+    w = fo.philox4x32_10(np.uint32(3), np.uint32(5), np.uint32(1 * 3 + 2), np.uint32(7), 0x89abcdef, 0x01234567)
+    assert bool(keep[1, 2, 13, 22]) == (((int(w[1]) >> 16) & 255) >= 64)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.75) < 0.02                      # P(keep) = 1 - p
+    k0, _ = fo.dropout_keep_mask(1, 1, 8, 8, 0.0, seed=1)
+    assert k0.all()                                     # p = 0 keeps everything
+    k2, _ = fo.dropout_keep_mask(2, 3, 37, 50, 0.25, seed=0x123456789abcdef, offset=8)
+    assert not torch.equal(keep, k2)                    # a different offset is a different mask
