@@ -30,7 +30,7 @@ def _is_dropout_variant(name):
 def test_library_contains_the_expected_kernels():
     ks = codeobj.kernels()
     names = " ".join(k["name"] for k in ks)
-    for stem in ("fa_fwd_kernel", "fa_fwd2_kernel", "fa_bwd_dq_kernel", "fa_bwd_dq2_kernel", "fa_bwd_dq3_kernel",
+    for stem in ("fa_fwd_kernel", "fa_fwd2_kernel", "fa_fwd3_kernel", "fa_bwd_dq_kernel", "fa_bwd_dq2_kernel", "fa_bwd_dq3_kernel",
                  "fa_bwd_dkv_kernel", "fa_bwd_dkv2_kernel"):
         assert stem in names, stem
     assert len(ks) >= 40
