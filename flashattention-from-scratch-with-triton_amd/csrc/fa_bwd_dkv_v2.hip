@@ -24,6 +24,9 @@ namespace fa {
 #ifndef FA_DKV_BQ
 #define FA_DKV_BQ 128  // query rows per LDS tile
 #endif
+#ifndef FA_DKV_STAGGER
+#define FA_DKV_STAGGER 2  // block iteration at which waves 2, 3 issue their share of the next tile's DMA (0 = tile start)
+#endif
 
 template <int D_>
 struct Dkv2Cfg {
@@ -144,7 +147,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
 #pragma unroll
     for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
   const float c2 = p.scale * kLog2e;
+#ifdef FA_DKV_NOFOLD   // A/B hook: exact fma for the exponent argument also at bf16
+  constexpr bool FOLD = false;
+#else
   constexpr bool FOLD = T::kFoldScale;  // fa_common.h: the score chain starts from -LSE*log2e and K carries c2
+#endif
   const int ntiles = (Sq + C::BQ - 1) / C::BQ;
 
   // A ragged last query tile leaves its tail rows to an out-of-range DMA; make sure those LDS bytes
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
 
     // ---- DMA of one Q/dO tile + the row-constant load (one float per thread < 128) ----
     float rc = 0.f;
-    auto fetch_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    auto fetch_dma = [&](int t, int buf) __attribute__((always_inline)) {
 #ifdef FA_ABLATE_DMA
       if (t > t_start + 1) return;  // keep real (random) data in both buffers: zeros would raise the clock
 #endif
@@ -189,7 +196,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
         dma16(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_src[i] + do_delta + C::RPI * i * (do_rs - q_rs), soff_do);
       }
 #endif
-      rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4);
+    };
+    auto fetch_rc = [&](int t) __attribute__((always_inline)) { rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4); };
+    auto fetch_tile = [&](int t, int buf) __attribute__((always_inline)) {
+      fetch_dma(t, buf);
+      fetch_rc(t);
     };
     // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet
     auto commit_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     // still allocates registers, counts waits and pads hazards).  Left alone, hipcc reads each operand one or two
     // MFMAs before its use and every wave then sits on the LDS latency sixteen times per block; here the reads
     // are ~140 cycles ahead and the VALU work hides in the issue cycles the MFMAs leave free.
-    auto tile_pipelined = [&](auto buf_tag) __attribute__((always_inline)) {
+    auto tile_pipelined = [&](auto buf_tag, auto&& block_hook) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_tag)::value;
       constexpr int KS = C::KS, DB = C::DB;
       // slot map of one block: [0, P0) S, [P0, V0) dP (block b); [V0, K0) dV^T, [K0, NS) dK^T (block b-1)
@@ -356,6 +367,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b <= C::QB; ++b) {
+        block_hook(b);
         const bool cur = b < C::QB;   // block b exists: S / dP slots
         const bool prev = b > 0;      // block b-1 exists: dV / dK slots and its VALU work
         f32x16 sn, pn;                // FOLD: next block's starting accumulators (read under the dK slots)
@@ -438,13 +450,29 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     auto step_full = [&](int t, auto buf_tag) __attribute__((always_inline)) {
       constexpr int BUF = decltype(buf_tag)::value;
       const bool more = t + 1 < ntiles;
-      if (more) fetch_tile(t + 1, BUF ^ 1);
+      // Staggered DMA issue: the four waves of a workgroup run in lockstep (one barrier per tile), so issuing all 32
+      // LDS-DMA pieces of the next tile at the tile start makes them queue behind one another in the CU's address unit
+      // (stamps: ~100 cycles of wave time per 1-KiB piece).  Waves 0 and 1 issue theirs at the tile start, waves 2 and 3
+      // two block iterations later (still ~1000 cycles before the tile's closing vmcnt(0)): +1.5-1.7 % (A/B, round 2).
+      constexpr int kLateBlock = FA_DKV_STAGGER;
+      const bool early = kLateBlock == 0 || wave < 2;
+      if (more) {
+        fetch_rc(t + 1);
+        if (early) fetch_dma(t + 1, BUF ^ 1);
+      }
       FA_STAMP(0);  // DMA issue
 #ifdef FA_DKV_NO_PIPE
+      if (more && !early) fetch_dma(t + 1, BUF ^ 1);
 #pragma unroll
       for (int b = 0; b < C::QB; ++b) q_block(BUF, b, 0, std::false_type{});
 #else
-      tile_pipelined(buf_tag);
+      tile_pipelined(buf_tag, [&](int b) __attribute__((always_inline)) {
+        if (kLateBlock != 0 && b == kLateBlock && more && !early) {
+          __builtin_amdgcn_sched_barrier(0);
+          fetch_dma(t + 1, BUF ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
 #endif
       commit_tile(t + 1, BUF ^ 1, more);
       FA_STAMP(4);  // vmcnt(0) + row constants + barrier
