@@ -355,11 +355,16 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
       };
       f32x16 xP, dP_;               // previous block: exponent argument -> P, and dP - delta -> dS
       u32x4 pk[2], sk[2];           // previous block: packed P and dS fragments (k-steps 0, 1), built dword by dword
-      vec8 fr[4];                   // operand ring, four slots deep
+#ifndef FA_DKV_RING
+#define FA_DKV_RING 4
+#endif
+      constexpr int RD = FA_DKV_RING;  // operand ring depth (slots of read-ahead); must divide the slots per block
+      static_assert(NS % RD == 0, "ring depth must divide the slot count");
+      vec8 fr[RD];                  // operand ring
       f32x16 sacc, pacc;            // this block's accumulators
       f32x16 nl;                    // exact mode (!FOLD): -LSE*log2e of this block, added by an fma under the dK slots
 #pragma unroll
-      for (int s = 0; s < 4; ++s) fr[s] = frag(0, s);
+      for (int s = 0; s < RD; ++s) fr[s] = frag(0, s);
       if constexpr (FOLD) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) rowc(0, g, sacc, pacc);
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
         for (int s = 0; s < NS; ++s) {
           const bool active = s < V0 ? cur : prev;
           if (active) {
-            const vec8 a = fr[s & 3];
+            const vec8 a = fr[s % RD];
             if (s < P0) sacc = T::mfma(a, kf[s], sacc);
             else if (s < V0) pacc = T::mfma(a, vf[s - P0], pacc);
             else if (s < K0) dvacc[(s - V0) >> 1] = T::mfma(a, as_vec8<T>(pk[(s - V0) & 1]), dvacc[(s - V0) >> 1]);
@@ -392,9 +397,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
           }
           // operand four slots ahead (wraps into the next block's row fragments; none past the last block)
           {
-            const int ns = (s + 4) % NS, nb = b + (s + 4) / NS;
+            const int ns = (s + RD) % NS, nb = b + (s + RD) / NS;
             const bool exists = ns < V0 ? (nb < C::QB) : (nb >= 1 && nb <= C::QB);
-            if (exists) fr[s & 3] = frag(nb, ns);
+            if (exists) fr[s % RD] = frag(nb, ns);
           }
           if constexpr (FOLD) {  // next block's row constants, one group per 2*DB/4 dK slots
             if (s >= K0 && (s - K0) % (2 * DB / 4) == 0 && b + 1 < C::QB) rowc(b + 1, (s - K0) / (2 * DB / 4), sn, pn);
