@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const BatchHead ix = batch_head(bh, p.B, p.H, p.vl.cu_q != nullptr);
+  const int b_ = ix.b, h_ = ix.h;
   // variable-length launch (fa_kernels.h VarLen): this sequence's rows and lengths; surplus workgroups exit
   const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
   const int Sq = si.Sq, Sk = si.Sk;

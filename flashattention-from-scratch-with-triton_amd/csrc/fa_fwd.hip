@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const BatchHead ix = batch_head(bh, p.B, p.H, p.vl.cu_q != nullptr);
+  const int b_ = ix.b, h_ = ix.h;
   // variable-length launch: this sequence's rows and lengths come from cu_seqlens; the grid was sized for the longest
   // sequence, so workgroups past this one's own tile count have nothing to do
   const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);

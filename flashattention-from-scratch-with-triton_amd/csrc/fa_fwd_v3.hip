@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd3_kernel(FwdParams p) {
   const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const BatchHead ix = batch_head(bh, p.B, p.H, p.vl.cu_q != nullptr);
+  const int b_ = ix.b, h_ = ix.h;
   const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
   const int Sq = si.Sq, Sk = si.Sk;
   const int nq = (Sq + C::BM - 1) / C::BM;
