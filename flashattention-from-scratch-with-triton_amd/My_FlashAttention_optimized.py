@@ -33,7 +33,7 @@ _DTYPES = {torch.float16: _fa.FP16, torch.bfloat16: _fa.BF16}
 def _in_place(*tensors):
     """The reference makes every input contiguous (M:138-140,156): a 64 MiB copy per tensor at the headline size
     whenever Q/K/V are transposed views of a fused projection ([B,S,H,D] seen as [B,H,S,D]).  The kernels read such
-    views in place (fa_*_strided); only layouts they cannot address (non-unit head-dim stride, rows not 16-byte
+    views in place and write O / dQ / dK / dV in the same storage order (fa_*_strided); only layouts they cannot address (non-unit head-dim stride, rows not 16-byte
     multiples, a base pointer off a 16-byte boundary, K and V with different sequence strides) are still copied --
     into a fresh (hence aligned) allocation."""
     return tuple(t if _fa.strided_ok(t) else t.clone(memory_format=torch.contiguous_format) for t in tensors)

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355fa.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FP16, BF16 = 0, 1
 
 _vp, _i, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ulonglong
@@ -24,10 +24,10 @@ SIGNATURES = {
     "fa_fwd": (_i, [_vp] * 5 + [_i] * 7 + [_f, _vp]),
     "fa_bwd_dq": (_i, [_vp] * 8 + [_i] * 7 + [_f, _vp]),
     "fa_bwd_dkv": (_i, [_vp] * 8 + [_i] * 7 + [_f, _vp]),
-    # strided inputs: (ptr, strides) pairs for q, k, v (and dout), then the contiguous outputs
-    "fa_fwd_strided": (_i, [_vp, _sp] * 3 + [_vp, _vp] + [_i] * 7 + [_f, _vp]),
-    "fa_bwd_dq_strided": (_i, [_vp, _sp] * 3 + [_vp] + [_vp, _sp] + [_vp] * 3 + [_i] * 7 + [_f, _vp]),
-    "fa_bwd_dkv_strided": (_i, [_vp, _sp] * 4 + [_vp] * 4 + [_i] * 7 + [_f, _vp]),
+    # strided tensors: (ptr, strides) pairs for q, k, v, (o), (dout) and for the outputs o / dq / dk / dv
+    "fa_fwd_strided": (_i, [_vp, _sp] * 4 + [_vp] + [_i] * 7 + [_f, _vp]),
+    "fa_bwd_dq_strided": (_i, [_vp, _sp] * 5 + [_vp] + [_vp, _sp] + [_vp] + [_i] * 7 + [_f, _vp]),
+    "fa_bwd_dkv_strided": (_i, [_vp, _sp] * 4 + [_vp] * 2 + [_vp, _sp] * 2 + [_i] * 7 + [_f, _vp]),
     # variable-length: packed [total, H, D] tensors, then cu_seqlens_q, cu_seqlens_k (device int32), then
     # batch, H, total_q, total_k, max_seqlen_q, max_seqlen_k, D, dtype, causal, scale, stream
     "fa_fwd_varlen": (_i, [_vp] * 5 + [_vp] * 2 + [_i] * 9 + [_f, _vp]),

@@ -44,11 +44,14 @@ int check_common(const char* fn, int B, int H, int Sq, int Sk, int D, int dtype)
 }
 
 // element strides {batch, head, seq} of a [B, H, S, D] input (NULL = contiguous) -> byte layout
-int make_layout(const char* fn, const long long* st, int H, int S, int D, fa::TensorLayout* out) {
+// An OUTPUT (B, extent of the batch dim, given): no broadcast strides -- every (batch, head, row) must be its own memory.
+int make_layout(const char* fn, const long long* st, int H, int S, int D, fa::TensorLayout* out, int out_B = 0) {
   if (!st) {
     *out = fa::contiguous_layout(H, S, D);
     return 0;
   }
+  if (out_B && ((out_B > 1 && st[0] == 0) || (H > 1 && st[1] == 0)))
+    return fail(MI355FA_ERR_STRIDE, "%s: an output cannot have a zero batch / head stride", fn);
   // batch / head strides may be 0 (an expanded K/V shared by several heads, MQA / GQA style); rows must not overlap
   for (int i = 0; i < 3; ++i)
     if (st[i] < 0 || (st[i] & 7) != 0)
@@ -114,8 +117,8 @@ int fa_supported(int D, int dtype) {
 }
 
 int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides, const void* v,
-                   const long long* v_strides, void* o, float* lse, int B, int H, int S_q, int S_k, int D, int dtype,
-                   int causal, float scale, void* stream) {
+                   const long long* v_strides, void* o, const long long* o_strides, float* lse, int B, int H, int S_q,
+                   int S_k, int D, int dtype, int causal, float scale, void* stream) {
   if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd");
   if (int rc = check_common("fa_fwd", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
@@ -125,7 +128,7 @@ int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, con
   if (int rc = make_layout("fa_fwd", k_strides, H, S_k, D, &p.lk)) return rc;
   if (int rc = make_layout("fa_fwd", v_strides, H, S_k, D, &p.lv)) return rc;
   if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_fwd");
-  p.lo = fa::contiguous_layout(H, S_q, D);
+  if (int rc = make_layout("fa_fwd", o_strides, H, S_q, D, &p.lo, B)) return rc;
   p.lse_sb = (long long)H * S_q;
   p.lse_sh = S_q;
   hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
@@ -135,13 +138,14 @@ int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, con
 
 int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
            int dtype, int causal, float scale, void* stream) {
-  return fa_fwd_strided(q, nullptr, k, nullptr, v, nullptr, o, lse, B, H, S_q, S_k, D, dtype, causal, scale, stream);
+  return fa_fwd_strided(q, nullptr, k, nullptr, v, nullptr, o, nullptr, lse, B, H, S_q, S_k, D, dtype, causal, scale, stream);
 }
 
 int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
-                      const void* v, const long long* v_strides, const void* o, const void* dout,
-                      const long long* dout_strides, const float* lse, void* dq, float* delta, int B, int H, int S_q,
-                      int S_k, int D, int dtype, int causal, float scale, void* stream) {
+                      const void* v, const long long* v_strides, const void* o, const long long* o_strides,
+                      const void* dout, const long long* dout_strides, const float* lse, void* dq,
+                      const long long* dq_strides, float* delta, int B, int H, int S_q, int S_k, int D, int dtype,
+                      int causal, float scale, void* stream) {
   if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq");
   if (int rc = check_common("fa_bwd_dq", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
@@ -154,6 +158,8 @@ int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, 
   if (int rc = make_layout("fa_bwd_dq", dout_strides, H, S_q, D, &p.ldo)) return rc;
   if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dq");
   set_contiguous_outputs(&p, H, S_q, S_k, D);
+  if (int rc = make_layout("fa_bwd_dq", o_strides, H, S_q, D, &p.lo)) return rc;
+  if (int rc = make_layout("fa_bwd_dq", dq_strides, H, S_q, D, &p.ldq, B)) return rc;
   hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
   return 0;
@@ -161,14 +167,15 @@ int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, 
 
 int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
               float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream) {
-  return fa_bwd_dq_strided(q, nullptr, k, nullptr, v, nullptr, o, dout, nullptr, lse, dq, delta, B, H, S_q, S_k, D, dtype,
-                           causal, scale, stream);
+  return fa_bwd_dq_strided(q, nullptr, k, nullptr, v, nullptr, o, nullptr, dout, nullptr, lse, dq, nullptr, delta, B, H, S_q,
+                           S_k, D, dtype, causal, scale, stream);
 }
 
 int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
                        const void* v, const long long* v_strides, const void* dout, const long long* dout_strides,
-                       const float* lse, const float* delta, void* dk, void* dv, int B, int H, int S_q, int S_k, int D,
-                       int dtype, int causal, float scale, void* stream) {
+                       const float* lse, const float* delta, void* dk, const long long* dk_strides, void* dv,
+                       const long long* dv_strides, int B, int H, int S_q, int S_k, int D, int dtype, int causal,
+                       float scale, void* stream) {
   if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv");
   if (int rc = check_common("fa_bwd_dkv", B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
@@ -181,6 +188,8 @@ int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k,
   if (int rc = make_layout("fa_bwd_dkv", dout_strides, H, S_q, D, &p.ldo)) return rc;
   if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dkv");
   set_contiguous_outputs(&p, H, S_q, S_k, D);
+  if (int rc = make_layout("fa_bwd_dkv", dk_strides, H, S_k, D, &p.ldk, B)) return rc;
+  if (int rc = make_layout("fa_bwd_dkv", dv_strides, H, S_k, D, &p.ldv, B)) return rc;
   hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
   return 0;
@@ -189,8 +198,8 @@ int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k,
 int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
                void* stream) {
-  return fa_bwd_dkv_strided(q, nullptr, k, nullptr, v, nullptr, dout, nullptr, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype,
-                            causal, scale, stream);
+  return fa_bwd_dkv_strided(q, nullptr, k, nullptr, v, nullptr, dout, nullptr, lse, delta, dk, nullptr, dv, nullptr, B, H, S_q,
+                            S_k, D, dtype, causal, scale, stream);
 }
 
 // ---- variable-length ("varlen") entry points: packed [total, H, D] tensors + cu_seqlens (include/mi355fa.h) ----

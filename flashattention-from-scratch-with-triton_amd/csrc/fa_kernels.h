@@ -75,12 +75,12 @@ struct FwdParams {
   void* dbg;     // diagnostic builds (-DFA_STAMPS) only: cycle-stamp buffer, else unused
   int pair;      // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
   TensorLayout lq, lk, lv;  // K and V share their row stride (checked by the C ABI)
-  TensorLayout lo;          // output O: contiguous [B, H, S, D] for the reference's launch, packed rows for varlen
+  TensorLayout lo;          // output O: contiguous [B, H, S, D] for the reference's launch, strided (fa_fwd_strided), packed rows for varlen
   long long lse_sb, lse_sh; // LSE element strides per batch / head (rows of one (batch, head) are contiguous)
   VarLen vl;
   DropoutParams drop;
   bool all_contiguous(int D) const {
-    return !vl.cu_q && lq.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
+    return !vl.cu_q && lq.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D) && lo.contiguous(H, Sq, D);
   }
 };
 
@@ -101,12 +101,15 @@ struct BwdParams {
   void* dbg;        // diagnostic builds (-DFA_STAMPS) only
   int pair;         // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
   TensorLayout lq, lk, lv, ldo;  // K and V share their row stride (checked by the C ABI)
-  TensorLayout lo, ldq, ldk, ldv;  // O (input of the dQ kernel) and the gradient outputs: contiguous, or packed rows (varlen)
+  TensorLayout lo, ldq, ldk, ldv;  // O (input of the dQ kernel) and the gradient outputs: contiguous, strided, or packed rows (varlen)
   long long lse_sb, lse_sh;        // LSE / delta element strides per batch / head
   VarLen vl;
   DropoutParams drop;
   bool all_contiguous(int D) const {
-    return !vl.cu_q && lq.contiguous(H, Sq, D) && ldo.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D);
+    // o / dq are unset (zero) in a dK/dV launch and dk / dv in a dQ launch: only the tensors a kernel touches count
+    return !vl.cu_q && lq.contiguous(H, Sq, D) && ldo.contiguous(H, Sq, D) && lk.contiguous(H, Sk, D) && lv.contiguous(H, Sk, D) &&
+           (!dq || (lo.contiguous(H, Sq, D) && ldq.contiguous(H, Sq, D))) &&
+           (!dk || (ldk.contiguous(H, Sk, D) && ldv.contiguous(H, Sk, D)));
   }
 };
 

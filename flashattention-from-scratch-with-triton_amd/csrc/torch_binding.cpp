@@ -71,6 +71,18 @@ struct Strides3 {
   }
 };
 
+// Output for an input the kernels read in place: the input's own memory order (what empty_like gives a dense view --
+// the reference allocates with empty_like too, M:24,71-73, but only after its .contiguous() copies), so a model that keeps
+// [B, S, H, D] activations gets O and the gradients back in that order and never transposes.  Layouts the kernels cannot
+// write (a broadcast stride, a head dim that does not stay innermost) get the contiguous tensor.
+Tensor out_like(const Tensor& t) {
+  if (!t.is_contiguous()) {
+    Tensor o = at::empty_like(t);
+    if (o.stride(3) == 1 && o.is_non_overlapping_and_dense() && strided_ok(o)) return o;
+  }
+  return torch::empty(t.sizes(), t.options());
+}
+
 int dtype_code(const Tensor& t) {
   if (t.scalar_type() == at::kHalf) return MI355FA_FP16;
   if (t.scalar_type() == at::kBFloat16) return MI355FA_BF16;
@@ -99,10 +111,10 @@ std::tuple<Tensor, Tensor> forward_launch(const Tensor& Q, const Tensor& K, cons
   const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
   const int dt = dtype_code(Q);
   c10::OptionalDeviceGuard guard(Q.device());
-  Tensor O = torch::empty({B, H, Sq, D}, Q.options());
+  Tensor O = out_like(Q);
   Tensor LSE = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
-  Strides3 sq(Q), sk(K), sv(V);
-  check_rc(fa_fwd_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(),
+  Strides3 sq(Q), sk(K), sv(V), so(O);
+  check_rc(fa_fwd_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(), so.ptr,
                           (float*)LSE.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
                           (float)(1.0 / std::sqrt((double)D)), current_stream(Q)),
            "fa_fwd");
@@ -124,11 +136,13 @@ std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor
   const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
   const int dt = dtype_code(Q);
   c10::OptionalDeviceGuard guard(Q.device());
-  Tensor O = (O_.is_contiguous() && reinterpret_cast<uintptr_t>(O_.data_ptr()) % 16 == 0)
-                 ? O_
-                 : O_.clone(at::MemoryFormat::Contiguous);
+  Tensor O = in_place(O_);
   Tensor dQ, dK, dV;
-  if (Sq == Sk) {  // self-attention: one allocation for the three gradients (M:71-73 makes three)
+  if (!Q.is_contiguous() || !K.is_contiguous() || !V.is_contiguous()) {  // each gradient in its input's memory order
+    dQ = out_like(Q);
+    dK = out_like(K);
+    dV = out_like(V);
+  } else if (Sq == Sk) {  // self-attention: one allocation for the three gradients (M:71-73 makes three)
     Tensor g = torch::empty({3, B, H, Sq, D}, Q.options());
     dQ = g.select(0, 0);
     dK = g.select(0, 1);
@@ -140,16 +154,16 @@ std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor
     dV = g.select(0, 1);
   }
   Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
-  Strides3 sq(Q), sk(K), sv(V), sdo(dO);
+  Strides3 sq(Q), sk(K), sv(V), so(O), sdo(dO), sdq(dQ), sdk(dK), sdv(dV);
   void* st = current_stream(Q);
   const float scale = (float)(1.0 / std::sqrt((double)D));
-  check_rc(fa_bwd_dq_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(), dO.data_ptr(),
-                             sdo.ptr, (const float*)LSE.data_ptr(), dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H,
-                             (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
+  check_rc(fa_bwd_dq_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(), so.ptr,
+                             dO.data_ptr(), sdo.ptr, (const float*)LSE.data_ptr(), dQ.data_ptr(), sdq.ptr,
+                             (float*)delta.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
            "fa_bwd_dq");
   check_rc(fa_bwd_dkv_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, dO.data_ptr(), sdo.ptr,
-                              (const float*)LSE.data_ptr(), (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                              (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
+                              (const float*)LSE.data_ptr(), (const float*)delta.data_ptr(), dK.data_ptr(), sdk.ptr,
+                              dV.data_ptr(), sdv.ptr, (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
            "fa_bwd_dkv");
   return {dQ, dK, dV};
 }

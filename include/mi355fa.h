@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355FA_ABI_VERSION 4
+#define MI355FA_ABI_VERSION 5
 
 /* dtype codes */
 #define MI355FA_FP16 0
@@ -77,29 +77,32 @@ int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout,
                int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
                void* stream);
 
-/* ---- strided inputs -------------------------------------------------------------------------
+/* ---- strided tensors ------------------------------------------------------------------------
  * The reference's binding makes every input contiguous first (code/My_FlashAttention_optimized.py:138-140,156 --
- * a 64 MiB copy per tensor at the headline size whenever Q/K/V are transposed views of a fused projection).
- * The *_strided entry points read such views in place.  Each INPUT operand [B, H, S, D] gets an array of three
- * ELEMENT strides {batch, head, sequence}; the head-dim stride is 1.  NULL = contiguous.  Example: a [B, S, H, D]
- * buffer viewed as [B, H, S, D] has {S*H*D, D, H*D}.  Every stride must be a multiple of 8 elements (16-byte rows);
- * the batch and head strides may be 0 (one K/V head expanded over several query heads), the sequence stride must be
- * at least D, and K, V must share their sequence stride.  Outputs (o, lse, dq, delta, dk, dv) and the `o`
- * argument of fa_bwd_dq_strided (the tensor fa_fwd* wrote) stay contiguous.  Everything else is as above.
+ * a 64 MiB copy per tensor at the headline size whenever Q/K/V are transposed views of a fused projection) and
+ * allocates its outputs with empty_like.  The *_strided entry points read such views in place and write O / dQ / dK / dV
+ * in whatever layout the caller allocated (e.g. the inputs' own, so a [B, S, H, D] model never transposes anything).
+ * Each [B, H, S, D] operand gets an array of three ELEMENT strides {batch, head, sequence}; the head-dim stride is 1.
+ * NULL = contiguous.  Example: a [B, S, H, D] buffer viewed as [B, H, S, D] has {S*H*D, D, H*D}.  Every stride must be a
+ * multiple of 8 elements (16-byte rows) and the sequence stride at least D; K, V must share their sequence stride.
+ * INPUTS may have a batch / head stride of 0 (one K/V head expanded over several query heads).  OUTPUTS (o, dq, dk, dv)
+ * may not, and their rows must not overlap (not checked beyond the zero strides).  `o_strides` of fa_bwd_dq_strided
+ * describes the O tensor fa_fwd* wrote.  lse and delta stay contiguous [B, H, S_q].  Everything else is as above.
  */
 int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
-                   const void* v, const long long* v_strides, void* o, float* lse,
+                   const void* v, const long long* v_strides, void* o, const long long* o_strides, float* lse,
                    int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
 
 int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
-                      const void* v, const long long* v_strides, const void* o,
+                      const void* v, const long long* v_strides, const void* o, const long long* o_strides,
                       const void* dout, const long long* dout_strides,
-                      const float* lse, void* dq, float* delta,
+                      const float* lse, void* dq, const long long* dq_strides, float* delta,
                       int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
 
 int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
                        const void* v, const long long* v_strides, const void* dout, const long long* dout_strides,
-                       const float* lse, const float* delta, void* dk, void* dv,
+                       const float* lse, const float* delta, void* dk, const long long* dk_strides,
+                       void* dv, const long long* dv_strides,
                        int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream);
 
 /* ---- Variable-length sequences (the extension the reference names as an exercise,

@@ -390,6 +390,11 @@ def test_strided_views_are_read_in_place_and_bit_identical(D, causal, dtype, imp
     g2 = M.flash_attention_backward(Qv.contiguous(), Kv.contiguous(), Vv.contiguous(), O2, dOv.contiguous(), L2, causal)
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+    # outputs come back in their input's memory order (what empty_like gives a view, M:24,71-73): dense [B, S, H, D]
+    for t in (O1,) + tuple(g1):
+        assert t.shape == Qv.shape and t.transpose(1, 2).is_contiguous()
+    for t in (O2,) + tuple(g2):
+        assert t.is_contiguous()
     # autograd level: gradients flow back to the fused buffer; no .contiguous() copy of the views is saved
     x = qkv.clone().requires_grad_(True)
     q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
@@ -414,6 +419,44 @@ def test_strided_views_are_read_in_place_and_bit_identical(D, causal, dtype, imp
     tol = 1e-3 if dtype == F16 else 5e-3
     for name, got in zip(("O", "dQ", "dK", "dV"), (O1,) + tuple(g1)):
         assert fo.rel_fro(gt[name], got.cpu()) < tol, name
+
+
+@pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
+def test_bshd_model_never_transposes_or_copies(dtype):
+    """A model that keeps [B, S, H, D] activations: q = x.transpose(1, 2) in, o.transpose(1, 2).reshape(B, S, H*D) out.
+    O is written in q's memory order, so the reshape is a view of O; the gradients are written in their inputs' order, so
+    autograd hands them to the [B, S, H, D] leaves as they are.  Bits equal the contiguous launch; an expanded K/V head
+    (zero head stride: not a layout an output can take) gets the contiguous gradient and autograd's sum over heads."""
+    M = _host()
+    B, H, S, D = 2, 4, 384, 64
+    torch.manual_seed(11)
+    xs = [torch.randn(B, S, H, D, device="cuda", dtype=dtype) for _ in range(3)]
+    dY = torch.randn(B, S, H * D, device="cuda", dtype=dtype)
+    leaves = [x.clone().requires_grad_(True) for x in xs]
+    q, k, v = (x.transpose(1, 2) for x in leaves)
+    o = M.flash_attention(q, k, v, True)
+    y = o.transpose(1, 2).reshape(B, S, H * D)
+    assert y.data_ptr() == o.data_ptr() and y.is_contiguous()              # a view: nothing was transposed
+    y.backward(dY)
+    twins = [x.transpose(1, 2).contiguous().requires_grad_(True) for x in xs]
+    o2 = M.flash_attention(*twins, True)
+    assert o2.is_contiguous() and torch.equal(o, o2)
+    o2.backward(dY.view(B, S, H, D).transpose(1, 2).contiguous())
+    for x, t in zip(leaves, twins):
+        assert x.grad.is_contiguous() and torch.equal(x.grad, t.grad.transpose(1, 2))
+    # grouped-query style: one K/V head expanded over the query heads
+    kv = [torch.randn(B, S, 1, D, device="cuda", dtype=dtype).requires_grad_(True) for _ in range(2)]
+    ql = xs[0].clone().requires_grad_(True)
+    o3 = M.flash_attention(ql.transpose(1, 2), *(t.transpose(1, 2).expand(B, H, S, D) for t in kv), True)
+    o3.transpose(1, 2).reshape(B, S, H * D).backward(dY)
+    kc = [t.detach().transpose(1, 2).expand(B, H, S, D).contiguous().requires_grad_(True) for t in kv]
+    qc = xs[0].transpose(1, 2).contiguous().requires_grad_(True)
+    o4 = M.flash_attention(qc, *kc, True)
+    o4.backward(dY.view(B, S, H, D).transpose(1, 2).contiguous())
+    assert torch.equal(o3, o4) and torch.equal(ql.grad, qc.grad.transpose(1, 2))
+    for t, c in zip(kv, kc):
+        want = c.grad.float().sum(1, keepdim=True).transpose(1, 2)           # [B, S, 1, D]
+        assert torch.allclose(t.grad.float(), want, rtol=2e-2, atol=2e-2)
 
 
 def test_layouts_the_kernels_cannot_address_are_copied_not_misread():

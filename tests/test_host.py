@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(raw, name), name
         assert name in fa.SIGNATURES, "python binding misses " + name
-    assert fa.lib.fa_abi_version() == 4
+    assert fa.lib.fa_abi_version() == 5
     assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_torch_binding_loads_and_matches_the_abi():
     import _mi355fa as fa
     import _mi355fa_torch as ext
-    assert ext.abi_version() == fa.ABI_VERSION == 4
+    assert ext.abi_version() == fa.ABI_VERSION == 5
     for name in ("flash_attention", "forward_launch", "backward_launch", "flash_attention_varlen", "varlen_forward_launch",
                  "varlen_backward_launch", "flash_attention_dropout", "dropout_forward_launch", "dropout_backward_launch"):
         assert callable(getattr(ext, name)), name
@@ -71,14 +71,19 @@ def test_argument_errors_are_rejected_before_launch():
     S3 = ctypes.c_longlong * 3
     ok = S3(8 * 2 * 64, 64, 2 * 64)          # a [B=1, S=8, H=2, D=64] buffer seen as [B, H, S, D]
     args = (1, 2, 8, 8, 64, 1, 0, 0.125, None)
-    assert L.fa_fwd_strided(None, ok, p, ok, p, ok, p, p, *args) == -1
-    assert L.fa_fwd_strided(p, S3(1024, 64, 100), p, ok, p, ok, p, p, *args) == -6      # 100 is not a multiple of 8
+    assert L.fa_fwd_strided(None, ok, p, ok, p, ok, p, None, p, *args) == -1
+    assert L.fa_fwd_strided(p, S3(1024, 64, 100), p, ok, p, ok, p, None, p, *args) == -6      # 100 is not a multiple of 8
     assert b"multiples of 8" in L.fa_last_error()
-    assert L.fa_fwd_strided(p, ok, p, ok, p, S3(1024, 64, 256), p, p, *args) == -6       # K and V row strides differ
+    assert L.fa_fwd_strided(p, ok, p, ok, p, S3(1024, 64, 256), p, None, p, *args) == -6       # K and V row strides differ
     assert b"K and V" in L.fa_last_error()
-    assert L.fa_fwd_strided(p, S3(1024, 64, 32), p, ok, p, ok, p, p, *args) == -6        # rows would overlap
-    assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, p, S3(-8, 64, 128), p, p, p, *args) == -6   # negative stride
-    assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, None, *args) == -1
+    assert L.fa_fwd_strided(p, S3(1024, 64, 32), p, ok, p, ok, p, None, p, *args) == -6        # rows would overlap
+    assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, None, p, S3(-8, 64, 128), p, p, None, p, *args) == -6   # negative stride
+    assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, None, None, None, *args) == -1
+    # outputs take strides too (ABI 5), but never a broadcast one: two heads would write the same rows
+    assert L.fa_fwd_strided(p, ok, p, ok, p, ok, p, S3(1024, 0, 128), p, *args) == -6
+    assert b"output" in L.fa_last_error()
+    assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, S3(1024, 0, 128), p, ok, p, p, S3(1024, 0, 128), p, *args) == -6
+    assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, ok, p, S3(1024, 64, 100), *args) == -6
 
 
 def test_schedule_table_lookup_and_override():
