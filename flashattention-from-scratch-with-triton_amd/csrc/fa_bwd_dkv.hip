@@ -287,13 +287,9 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
   using C = DkvCfg<D>;
   const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
   auto kern = fa_bwd_dkv_kernel<D, T, CAUSAL, DROP>;
-  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
-    static bool opted_in = false;    // (per template instance; a racing second call only repeats an idempotent setting)
-    if (!opted_in) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-      if (e != hipSuccess) return e;
-      opted_in = true;
-    }
+  if (C::LDS_BYTES > 48 * 1024) {
+    static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
+    if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES, opted_in)) return e;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();

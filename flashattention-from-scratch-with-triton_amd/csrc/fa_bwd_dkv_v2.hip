@@ -546,13 +546,9 @@ static hipError_t launch2(const BwdParams& p, hipStream_t s) {
 #else
   constexpr int pad = 0;
 #endif
-  if (C::LDS_BYTES + pad > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
-    static bool opted_in = false;        // (per template instance; a racing second call only repeats an idempotent setting)
-    if (!opted_in) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + pad);
-      if (e != hipSuccess) return e;
-      opted_in = true;
-    }
+  if (C::LDS_BYTES + pad > 48 * 1024) {
+    static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
+    if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES + pad, opted_in)) return e;
   }
   if (pad) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES + pad, s, p);

@@ -276,13 +276,9 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
     if (grid >= 3 * 256) return launch<D, T, CAUSAL, 3>(p, s);
   }
   auto kern = fa_bwd_dq_kernel<D, T, CAUSAL, OCC, DROP>;
-  if (C::LDS_BYTES > 48 * 1024) {  // opt in to the large dynamic LDS carve (160 KiB per CU on gfx950), once per kernel
-    static bool opted_in = false;    // (per template instance; a racing second call only repeats an idempotent setting)
-    if (!opted_in) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-      if (e != hipSuccess) return e;
-      opted_in = true;
-    }
+  if (C::LDS_BYTES > 48 * 1024) {
+    static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
+    if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES, opted_in)) return e;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
   return hipGetLastError();

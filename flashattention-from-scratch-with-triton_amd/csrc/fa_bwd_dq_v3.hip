@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq3_kernel(BwdParams p) {
                  f32x16& pX, u32x4 (&dk_in)[2], u32x4 (&dk_out)[2]) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_tag)::value, KB = decltype(kb_tag)::value;
     constexpr bool HAS_X = decltype(x_tag)::value, HAS_Q = decltype(q_tag)::value, NEXT_Q = decltype(nq_tag)::value;
-    constexpr int Q0 = 0, S0 = 2 * C::DB, P0 = S0 + C::KS, NS = C::NS;
+    constexpr int S0 = 2 * C::DB, P0 = S0 + C::KS, NS = C::NS;
     constexpr int PREV = (PH + 2) % 3;  // ring slot of tile t-1
     const FA_LDS char* kb_rows = smem + PH * C::TILE_BYTES + KB * 32 * C::ROWB;
     const FA_LDS char* vb_rows = smem + C::V_BASE + PH * C::TILE_BYTES + KB * 32 * C::ROWB;

@@ -113,6 +113,20 @@ struct BwdParams {
   }
 };
 
+// Opt a kernel in to a dynamic LDS carve above the 48 KiB default (160 KiB per CU on gfx950).  The attribute belongs to
+// the CURRENT device's copy of the function, so it is cached per (kernel template instance, device): `done` is that
+// instance's bit mask of devices already set.  A racing second call only repeats an idempotent setting.
+inline hipError_t opt_in_lds(const void* kern, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = dev < 64 ? 1ull << dev : 0;   // devices >= 64: never cached, always set
+  if (bit && (done.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  return e;
+}
+
 // ---- schedule selection: the counterpart of the reference's autotune key (S_q, S_k, D, is_causal), K:18-32 --------
 // A table generated offline (tools/tune.py -> fa_table.h) instead of a run-time search.  Schedule families:
 //   forward   1 = fa_fwd.hip      128-row workgroups, 32 rows per wave, up to 3 waves per SIMD  (D = 64, 128)
