@@ -193,6 +193,14 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
           pacc[4 * g + j] = DROP ? 0.f : d[j];
         }
       }
+      // DROP: one Philox call per lane and block -- registers 4g..4g+3 are query rows qb0 + 8g + 4h + 0..3 of key kw0 + r,
+      // i.e. byte (key & 3) of the four words of patch g, and the quad's four lanes (four consecutive keys) need the same
+      // four patches: lane j generates patch g = j (fa_common.h quad_bcast).  Issued here, beside the MFMA chains.
+      u32x4 mine = {0, 0, 0, 0};
+      if constexpr (DROP) {
+        const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+        mine = dropout_patch(dr, ((qb0 + 4 * h) >> 2) + 2 * (r & 3), (kw0 + r) >> 2, bh);
+      }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
@@ -217,9 +225,9 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       if constexpr (DROP) {
         const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
         const int key = kw0 + r;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u32x4 patch = dropout_patch(dr, (qb0 + 8 * g + 4 * h) >> 2, key >> 2, bh);
+        auto apply = [&](auto g_tag) __attribute__((always_inline)) {
+          constexpr int g = decltype(g_tag)::value;
+          const u32x4 patch = quad_bcast4<g>(mine);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {   // register 4g + j <-> query 4*qg + j: word j of the patch, byte key & 3
             const int i = 4 * g + j;
@@ -229,7 +237,11 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
             pacc[i] = pe * (dp + nd[i]);                       // dS = P o (dP - delta)
             sacc[i] = keep ? pe * dr.rp : 0.f;                 // dropped, rescaled P for dV
           }
-        }
+        };
+        apply(std::integral_constant<int, 0>{});
+        apply(std::integral_constant<int, 1>{});
+        apply(std::integral_constant<int, 2>{});
+        apply(std::integral_constant<int, 3>{});
       }
       const vec8 p0 = pack8<T, 0>(sacc), p1 = pack8<T, 1>(sacc);
       const vec8 s0 = pack8<T, 0>(pacc), s1 = pack8<T, 1>(pacc);

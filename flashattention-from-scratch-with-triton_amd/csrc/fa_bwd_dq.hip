@@ -194,6 +194,13 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
       }
+      // DROP: one Philox call per lane and block -- lane j of a quad generates patch g = j for the quad's four rows
+      // (fa_common.h quad_bcast); issued here so that its ~100 integer ops run beside the MFMA chains below
+      u32x4 mine = {0, 0, 0, 0};
+      if constexpr (DROP) {
+        const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+        mine = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), bh);
+      }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(kbp + row_off[ks]));
@@ -218,10 +225,9 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
       if constexpr (DROP) {
         const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
         const int qrow = qw0 + r;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u32x4 patch = dropout_patch(dr, qrow >> 2, (s0 + 32 * b + 8 * g + 4 * h) >> 2, bh);
-          const unsigned w = select_word(patch, qrow & 3);
+        auto apply = [&](auto g_tag) __attribute__((always_inline)) {
+          constexpr int g = decltype(g_tag)::value;
+          const unsigned w = select_word(quad_bcast4<g>(mine), qrow & 3);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
@@ -229,7 +235,11 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
             const float dp = keep ? pacc[i] * dr.rp : 0.f;   // dP = mask / (1 - p) o (dO V^T)
             sacc[i] = sacc[i] * (dp - delta);                // dS = P o (dP - delta)
           }
-        }
+        };
+        apply(std::integral_constant<int, 0>{});
+        apply(std::integral_constant<int, 1>{});
+        apply(std::integral_constant<int, 2>{});
+        apply(std::integral_constant<int, 3>{});
       }
       const vec8 d0 = pack8<T, 0>(sacc);
       const vec8 d1 = pack8<T, 1>(sacc);

@@ -256,8 +256,11 @@ FA_DEVINL float half_sum(float v) {
 // byte (k & 3) of word (q & 3).  A weight is KEPT iff its byte >= thresh (thresh = round(256 p), p quantised to 1/256)
 // and kept weights are scaled by rp = 256 / (256 - thresh).  In every kernel a lane's 16 accumulator registers of a
 // 32 x 32 block are four 1 x 4 (forward, dQ: lane = query) or 4 x 1 (dK/dV: lane = key) strips of four different
-// patches: four Philox calls per block and lane.  v_mul_hi / v_mul_lo are quarter rate on CDNA4: the dropout kernels
-// are several times slower than the plain ones, which are separate template instances and pay nothing.
+// patches g = 0..3 -- and the four lanes of a quad (lanes 4n..4n+3: four consecutive queries, or keys) hold strips of the
+// SAME four patches.  Lane j of the quad therefore generates patch g = j only and the quad exchanges the words with DPP
+// quad_perm broadcasts (quad_bcast): one Philox call per block and lane instead of four.  v_mul_hi / v_mul_lo are quarter
+// rate on CDNA4, so even that call is most of the dropout kernels' extra time; the plain kernels are separate template
+// instances and pay nothing.
 struct Dropout {
   unsigned thresh;            // 0 = no dropout (the plain kernels are launched)
   unsigned seed_lo, seed_hi;  // Philox key
@@ -268,8 +271,10 @@ FA_DEVINL u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3
   constexpr unsigned kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
 #pragma unroll
   for (int round = 0; round < 10; ++round) {
-    const unsigned hi0 = __umulhi(kM0, c0), lo0 = kM0 * c0;
-    const unsigned hi1 = __umulhi(kM1, c2), lo1 = kM1 * c2;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of v_mul_hi + v_mul_lo, all quarter rate
+    const unsigned long long p0 = (unsigned long long)kM0 * c0, p1 = (unsigned long long)kM1 * c2;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+    const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0;
     c1 = lo1;
@@ -283,6 +288,15 @@ FA_DEVINL u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3
 // the 4 x 4 patch of random bytes holding weights (4*qg.., 4*kg..) of (batch*head) slice `bh`
 FA_DEVINL u32x4 dropout_patch(const Dropout& d, int qg, int kg, int bh) {
   return philox4x32_10((unsigned)qg, (unsigned)kg, (unsigned)bh, d.offset, d.seed_lo, d.seed_hi);
+}
+// value of `v` in lane G of this lane's quad (all four lanes of the quad must be active: EXEC is full in these kernels)
+template <int G>
+FA_DEVINL unsigned quad_bcast(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, G * 0x55 /* quad_perm:[G,G,G,G] */, 0xF, 0xF, false);
+}
+template <int G>
+FA_DEVINL u32x4 quad_bcast4(const u32x4& v) {
+  return u32x4{quad_bcast<G>(v[0]), quad_bcast<G>(v[1]), quad_bcast<G>(v[2]), quad_bcast<G>(v[3])};
 }
 FA_DEVINL unsigned select_word(const u32x4& w, int idx) {  // idx in 0..3, lane dependent
   const unsigned lo = (idx & 1) ? w[1] : w[0], hi = (idx & 1) ? w[3] : w[2];

@@ -211,6 +211,16 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
       if (!use[0] && !use[1]) return;
     }
     f32x16 sacc[2];
+    // DROP: one Philox call per lane and key block -- registers 4g..4g+3 are keys s0 + 32b + 8g + 4h + 0..3 of row qw0 + r,
+    // i.e. word (row & 3) of patch g, and the quad's four lanes (four consecutive rows) need the same four patches: lane j
+    // generates patch g = j (fa_common.h quad_bcast).  Issued here so that its integer ops run beside the MFMA chains.
+    u32x4 mine[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if constexpr (DROP) {
+      const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (!(MASKED && !use[b])) mine[b] = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), bh);
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       if (MASKED && !use[b]) {
@@ -277,16 +287,19 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         if (MASKED && !use[b]) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u32x4 patch = dropout_patch(dr, qrow >> 2, (s0 + 32 * b + 8 * g + 4 * h) >> 2, bh);
-          const unsigned w = select_word(patch, qrow & 3);
+        auto apply = [&](auto g_tag) __attribute__((always_inline)) {
+          constexpr int g = decltype(g_tag)::value;
+          const unsigned w = select_word(quad_bcast4<g>(mine[b]), qrow & 3);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const bool keep = ((w >> (8 * j)) & 255u) >= dr.thresh;
             sacc[b][4 * g + j] = keep ? sacc[b][4 * g + j] * dr.rp : 0.f;
           }
-        }
+        };
+        apply(std::integral_constant<int, 0>{});
+        apply(std::integral_constant<int, 1>{});
+        apply(std::integral_constant<int, 2>{});
+        apply(std::integral_constant<int, 3>{});
       }
     }
     // ---- O^T += V^T P^T ----
