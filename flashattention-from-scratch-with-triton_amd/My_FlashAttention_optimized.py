@@ -103,23 +103,27 @@ def flash_attention(Q, K, V, is_causal=False):
     return _ext.flash_attention(Q, K, V, bool(is_causal))
 
 
-def flash_attention_varlen(Q, K, V, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal=False):
+def flash_attention_varlen(Q, K, V, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal=False,
+                           dropout_p=0.0, seed=0, offset=0):
     """Variable-length attention over PACKED sequences -- the extension the reference leaves as an exercise
     (Phase_6.md:119-178: "concatenate the batch into one long sequence and record where each sequence starts").
 
     Q: [total_q, H, D], K, V: [total_k, H, D] (fp16 / bf16, device); cu_seqlens_*: int32 device vectors of batch + 1
     prefix sums starting at 0; max_seqlen_*: Python ints >= the longest sequence (they size the launch grid).  Returns
     O [total_q, H, D]; differentiable w.r.t. Q, K, V.  Each sequence attends to itself only; is_causal applies each
-    sequence's own top-left aligned mask.  No padding is computed: workgroups beyond a sequence's length exit at once."""
+    sequence's own top-left aligned mask.  No padding is computed: workgroups beyond a sequence's length exit at once.
+    dropout_p / seed / offset: attention dropout as in flash_attention_dropout; the mask of sequence b is the one the same
+    sequence gets at batch index b of a padded [B, H, S, D] launch with the same (seed, offset)."""
     return _ext.flash_attention_varlen(Q, K, V, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), int(max_seqlen_k),
-                                       bool(is_causal))
+                                       bool(is_causal), float(dropout_p), int(seed), int(offset))
 
 
 def flash_attention_dropout(Q, K, V, is_causal=False, dropout_p=0.0, seed=0, offset=0):
     """Attention with dropout on the attention weights -- the other extension the reference leaves as an exercise
     (Phase_6.md:54-113): P is masked and rescaled by 1 / (1 - p) inside the tile loop, and the backward regenerates the
     SAME mask from (seed, offset) with Philox4x32-10 instead of storing it (include/mi355fa.h, fa_*_dropout, gives the
-    exact counter layout).  Q, K, V: [B, H, S, D] fp16 / bf16 device tensors; dropout_p in [0, 1), quantised to 1/256;
+    exact counter layout).  Q, K, V: [B, H, S, D] fp16 / bf16 device tensors (strided views are read in place, as in
+    flash_attention); dropout_p in [0, 1), quantised to 1/256;
     seed / offset: Python ints (the caller owns the RNG stream: pass a fresh offset per layer and step).  Differentiable
     w.r.t. Q, K, V.  dropout_p = 0 is flash_attention."""
     if dropout_p == 0.0:

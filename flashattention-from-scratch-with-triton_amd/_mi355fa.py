@@ -10,11 +10,31 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355fa.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FP16, BF16 = 0, 1
 
 _vp, _i, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ulonglong
 _sp = ctypes.POINTER(ctypes.c_longlong)   # const long long* strides (3 element strides) or NULL
+
+class Opts(ctypes.Structure):
+    """mi355fa_opts (include/mi355fa.h): strides, cu_seqlens and dropout in any combination for the fa_*_ex entry points.
+    `Opts.make(...)` zero-initialises and sets `size`."""
+    _fields_ = ([("size", ctypes.c_uint)] +
+                [(n, _sp) for n in ("q_strides", "k_strides", "v_strides", "o_strides", "dout_strides", "dq_strides",
+                                    "dk_strides", "dv_strides")] +
+                [("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp), ("total_q", _i), ("total_k", _i),
+                 ("p_drop", _f), ("seed", _u64), ("offset", _u64)])
+
+    @classmethod
+    def make(cls, **kw):
+        o = cls()
+        o.size = ctypes.sizeof(cls)
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+
+_op = ctypes.POINTER(Opts)
 
 # name -> (restype, argtypes); mirrors include/mi355fa.h one to one
 SIGNATURES = {
@@ -38,6 +58,10 @@ SIGNATURES = {
     "fa_fwd_dropout": (_i, [_vp] * 5 + [_i] * 7 + [_f, _f, _u64, _u64, _vp]),
     "fa_bwd_dq_dropout": (_i, [_vp] * 8 + [_i] * 7 + [_f, _f, _u64, _u64, _vp]),
     "fa_bwd_dkv_dropout": (_i, [_vp] * 8 + [_i] * 7 + [_f, _f, _u64, _u64, _vp]),
+    # general form: the plain signatures + const mi355fa_opts* (NULL = plain launch), stream
+    "fa_fwd_ex": (_i, [_vp] * 5 + [_i] * 7 + [_f, _op, _vp]),
+    "fa_bwd_dq_ex": (_i, [_vp] * 8 + [_i] * 7 + [_f, _op, _vp]),
+    "fa_bwd_dkv_ex": (_i, [_vp] * 8 + [_i] * 7 + [_f, _op, _vp]),
 }
 
 

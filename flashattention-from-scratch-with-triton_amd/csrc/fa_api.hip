@@ -63,14 +63,6 @@ int make_layout(const char* fn, const long long* st, int H, int S, int D, fa::Te
   return 0;
 }
 
-// the reference's output convention: contiguous [B, H, S, D] O / dQ / dK / dV, [B, H, S_q] LSE / delta
-void set_contiguous_outputs(fa::BwdParams* p, int H, int Sq, int Sk, int D) {
-  p->lo = p->ldq = fa::contiguous_layout(H, Sq, D);
-  p->ldk = p->ldv = fa::contiguous_layout(H, Sk, D);
-  p->lse_sb = (long long)H * Sq;
-  p->lse_sh = Sq;
-}
-
 // packed [total tokens, H, D] rows (varlen): no batch stride (the cu_seqlens arrays place each sequence), head stride D
 fa::TensorLayout packed_layout(int H, int D) { return fa::TensorLayout{0, (long long)D * 2, H * D * 2}; }
 
@@ -84,6 +76,19 @@ int check_varlen(const char* fn, const int* cu_q, const int* cu_k, int batch, in
   if ((long long)max_q * H * D * 2 > (1ll << 31) - 1 || (long long)max_k * H * D * 2 > (1ll << 31) - 1)
     return fail(MI355FA_ERR_SHAPE, "%s: one packed sequence exceeds 2^31 bytes", fn);
   return check_common(fn, batch, H, max_q, max_k, D, dtype);
+}
+
+// dropout state of a launch: p is quantised to multiples of 1/256 (include/mi355fa.h); p = 0 -> thresh 0 = plain kernels
+int make_dropout(const char* fn, float p_drop, unsigned long long seed, unsigned long long offset, fa::DropoutParams* out) {
+  if (!(p_drop >= 0.f) || p_drop >= 1.f) return fail(MI355FA_ERR_SHAPE, "%s: dropout probability must be in [0, 1)", fn);
+  unsigned thresh = (unsigned)(p_drop * 256.f + 0.5f);
+  if (thresh > 255u) thresh = 255u;
+  out->thresh = thresh;
+  out->seed_lo = (unsigned)seed;
+  out->seed_hi = (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32);
+  out->offset = (unsigned)offset;
+  out->rp = 256.f / (256.f - (float)thresh);
+  return 0;
 }
 
 }  // namespace
@@ -116,227 +121,256 @@ int fa_supported(int D, int dtype) {
   return (D == 64 || D == 128) && (dtype == MI355FA_FP16 || dtype == MI355FA_BF16);
 }
 
-int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides, const void* v,
-                   const long long* v_strides, void* o, const long long* o_strides, float* lse, int B, int H, int S_q,
-                   int S_k, int D, int dtype, int causal, float scale, void* stream) {
-  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd");
-  if (int rc = check_common("fa_fwd", B, H, S_q, S_k, D, dtype)) return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd");
-  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg, 0};
-  if (int rc = make_layout("fa_fwd", q_strides, H, S_q, D, &p.lq)) return rc;
-  if (int rc = make_layout("fa_fwd", k_strides, H, S_k, D, &p.lk)) return rc;
-  if (int rc = make_layout("fa_fwd", v_strides, H, S_k, D, &p.lv)) return rc;
-  if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_fwd");
-  if (int rc = make_layout("fa_fwd", o_strides, H, S_q, D, &p.lo, B)) return rc;
-  p.lse_sb = (long long)H * S_q;
-  p.lse_sh = S_q;
-  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_fwd launch");
+// ---- the one implementation: every public entry point below fills an mi355fa_opts and lands here -------------------
+// `fn` = the public name, for the error text.  Fixed-length: [B, H, S, D] tensors, optional per-tensor strides.  Varlen
+// (opts->cu_seqlens_q != NULL): packed [total, H, D] tensors, B = batch, S_q / S_k = max_seqlen_q / max_seqlen_k.
+// Dropout (opts->p_drop > 0) composes with both.
+static int read_opts(const char* fn, const mi355fa_opts* in, mi355fa_opts* o) {
+  *o = mi355fa_opts{};
+  if (!in) return 0;
+  if (in->size != sizeof(mi355fa_opts))
+    return fail(MI355FA_ERR_SHAPE, "%s: mi355fa_opts.size does not match this library (set it to sizeof(mi355fa_opts))", fn);
+  *o = *in;
+  if ((o->cu_seqlens_q == nullptr) != (o->cu_seqlens_k == nullptr))
+    return fail(MI355FA_ERR_NULL, "%s: cu_seqlens_q and cu_seqlens_k must be given together", fn);
+  if (o->cu_seqlens_q && (o->q_strides || o->k_strides || o->v_strides || o->o_strides || o->dout_strides || o->dq_strides ||
+                          o->dk_strides || o->dv_strides))
+    return fail(MI355FA_ERR_STRIDE, "%s: packed variable-length tensors take no strides", fn);
   return 0;
 }
 
-int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
-           int dtype, int causal, float scale, void* stream) {
-  return fa_fwd_strided(q, nullptr, k, nullptr, v, nullptr, o, nullptr, lse, B, H, S_q, S_k, D, dtype, causal, scale, stream);
+static int fwd_impl(const char* fn, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q,
+                    int S_k, int D, int dtype, int causal, float scale, const mi355fa_opts* opts, void* stream) {
+  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", fn);
+  mi355fa_opts x;
+  if (int rc = read_opts(fn, opts, &x)) return rc;
+  if (x.cu_seqlens_q) {
+    if (int rc = check_varlen(fn, x.cu_seqlens_q, x.cu_seqlens_k, B, H, x.total_q, x.total_k, S_q, S_k, D, dtype)) return rc;
+  } else if (int rc = check_common(fn, B, H, S_q, S_k, D, dtype)) {
+    return rc;
+  }
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  if (x.cu_seqlens_q) {
+    p.lq = p.lk = p.lv = p.lo = packed_layout(H, D);
+    p.lse_sb = 0;
+    p.lse_sh = x.total_q;
+    p.vl = fa::VarLen{x.cu_seqlens_q, x.cu_seqlens_k};
+  } else {
+    if (int rc = make_layout(fn, x.q_strides, H, S_q, D, &p.lq)) return rc;
+    if (int rc = make_layout(fn, x.k_strides, H, S_k, D, &p.lk)) return rc;
+    if (int rc = make_layout(fn, x.v_strides, H, S_k, D, &p.lv)) return rc;
+    if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", fn);
+    if (int rc = make_layout(fn, x.o_strides, H, S_q, D, &p.lo, B)) return rc;
+    p.lse_sb = (long long)H * S_q;
+    p.lse_sh = S_q;
+  }
+  if (int rc = make_dropout(fn, x.p_drop, x.seed, x.offset, &p.drop)) return rc;
+  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, fn);
+  return 0;
 }
 
+// the layouts, sequence table and dropout state shared by the two backward launches
+static int bwd_fill(const char* fn, fa::BwdParams* p, const mi355fa_opts& x, int B, int H, int S_q, int S_k, int D, int dtype) {
+  if (x.cu_seqlens_q) {
+    if (int rc = check_varlen(fn, x.cu_seqlens_q, x.cu_seqlens_k, B, H, x.total_q, x.total_k, S_q, S_k, D, dtype)) return rc;
+    p->lq = p->lk = p->lv = p->ldo = p->lo = p->ldq = p->ldk = p->ldv = packed_layout(H, D);
+    p->lse_sb = 0;
+    p->lse_sh = x.total_q;
+    p->vl = fa::VarLen{x.cu_seqlens_q, x.cu_seqlens_k};
+  } else {
+    if (int rc = check_common(fn, B, H, S_q, S_k, D, dtype)) return rc;
+    if (int rc = make_layout(fn, x.q_strides, H, S_q, D, &p->lq)) return rc;
+    if (int rc = make_layout(fn, x.k_strides, H, S_k, D, &p->lk)) return rc;
+    if (int rc = make_layout(fn, x.v_strides, H, S_k, D, &p->lv)) return rc;
+    if (int rc = make_layout(fn, x.dout_strides, H, S_q, D, &p->ldo)) return rc;
+    if (p->lk.rs != p->lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", fn);
+    if (int rc = make_layout(fn, x.o_strides, H, S_q, D, &p->lo)) return rc;
+    if (int rc = make_layout(fn, x.dq_strides, H, S_q, D, &p->ldq, B)) return rc;
+    if (int rc = make_layout(fn, x.dk_strides, H, S_k, D, &p->ldk, B)) return rc;
+    if (int rc = make_layout(fn, x.dv_strides, H, S_k, D, &p->ldv, B)) return rc;
+    p->lse_sb = (long long)H * S_q;
+    p->lse_sh = S_q;
+  }
+  return make_dropout(fn, x.p_drop, x.seed, x.offset, &p->drop);
+}
+
+static int dq_impl(const char* fn, const void* q, const void* k, const void* v, const void* o, const void* dout,
+                   const float* lse, void* dq, float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal,
+                   float scale, const mi355fa_opts* opts, void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", fn);
+  mi355fa_opts x;
+  if (int rc = read_opts(fn, opts, &x)) return rc;
+  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  if (int rc = bwd_fill(fn, &p, x, B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
+      misaligned(dq) || misaligned(delta))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, fn);
+  return 0;
+}
+
+static int dkv_impl(const char* fn, const void* q, const void* k, const void* v, const void* dout, const float* lse,
+                    const float* delta, void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal,
+                    float scale, const mi355fa_opts* opts, void* stream) {
+  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", fn);
+  mi355fa_opts x;
+  if (int rc = read_opts(fn, opts, &x)) return rc;
+  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
+  if (int rc = bwd_fill(fn, &p, x, B, H, S_q, S_k, D, dtype)) return rc;
+  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
+      misaligned(dk) || misaligned(dv))
+    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, fn);
+  return 0;
+}
+
+static mi355fa_opts base_opts() {
+  mi355fa_opts x{};
+  x.size = sizeof(mi355fa_opts);
+  return x;
+}
+
+// ---- general, composable entry points ------------------------------------------------------------------------------
+int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+              int dtype, int causal, float scale, const mi355fa_opts* opts, void* stream) {
+  return fwd_impl("fa_fwd_ex", q, k, v, o, lse, B, H, S_q, S_k, D, dtype, causal, scale, opts, stream);
+}
+int fa_bwd_dq_ex(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                 float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+                 const mi355fa_opts* opts, void* stream) {
+  return dq_impl("fa_bwd_dq_ex", q, k, v, o, dout, lse, dq, delta, B, H, S_q, S_k, D, dtype, causal, scale, opts, stream);
+}
+int fa_bwd_dkv_ex(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                  void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+                  const mi355fa_opts* opts, void* stream) {
+  return dkv_impl("fa_bwd_dkv_ex", q, k, v, dout, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype, causal, scale, opts, stream);
+}
+
+// ---- the reference's three launches (contiguous [B, H, S, D]) ------------------------------------------------------
+int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+           int dtype, int causal, float scale, void* stream) {
+  return fwd_impl("fa_fwd", q, k, v, o, lse, B, H, S_q, S_k, D, dtype, causal, scale, nullptr, stream);
+}
+int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+              float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream) {
+  return dq_impl("fa_bwd_dq", q, k, v, o, dout, lse, dq, delta, B, H, S_q, S_k, D, dtype, causal, scale, nullptr, stream);
+}
+int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+               void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+               void* stream) {
+  return dkv_impl("fa_bwd_dkv", q, k, v, dout, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype, causal, scale, nullptr, stream);
+}
+
+// ---- strided tensors ------------------------------------------------------------------------------------------------
+int fa_fwd_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides, const void* v,
+                   const long long* v_strides, void* o, const long long* o_strides, float* lse, int B, int H, int S_q,
+                   int S_k, int D, int dtype, int causal, float scale, void* stream) {
+  mi355fa_opts x = base_opts();
+  x.q_strides = q_strides;
+  x.k_strides = k_strides;
+  x.v_strides = v_strides;
+  x.o_strides = o_strides;
+  return fwd_impl("fa_fwd", q, k, v, o, lse, B, H, S_q, S_k, D, dtype, causal, scale, &x, stream);
+}
 int fa_bwd_dq_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
                       const void* v, const long long* v_strides, const void* o, const long long* o_strides,
                       const void* dout, const long long* dout_strides, const float* lse, void* dq,
                       const long long* dq_strides, float* delta, int B, int H, int S_q, int S_k, int D, int dtype,
                       int causal, float scale, void* stream) {
-  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq");
-  if (int rc = check_common("fa_bwd_dq", B, H, S_q, S_k, D, dtype)) return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
-      misaligned(dq) || misaligned(delta))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq");
-  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
-  if (int rc = make_layout("fa_bwd_dq", q_strides, H, S_q, D, &p.lq)) return rc;
-  if (int rc = make_layout("fa_bwd_dq", k_strides, H, S_k, D, &p.lk)) return rc;
-  if (int rc = make_layout("fa_bwd_dq", v_strides, H, S_k, D, &p.lv)) return rc;
-  if (int rc = make_layout("fa_bwd_dq", dout_strides, H, S_q, D, &p.ldo)) return rc;
-  if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dq");
-  set_contiguous_outputs(&p, H, S_q, S_k, D);
-  if (int rc = make_layout("fa_bwd_dq", o_strides, H, S_q, D, &p.lo)) return rc;
-  if (int rc = make_layout("fa_bwd_dq", dq_strides, H, S_q, D, &p.ldq, B)) return rc;
-  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq launch");
-  return 0;
+  mi355fa_opts x = base_opts();
+  x.q_strides = q_strides;
+  x.k_strides = k_strides;
+  x.v_strides = v_strides;
+  x.o_strides = o_strides;
+  x.dout_strides = dout_strides;
+  x.dq_strides = dq_strides;
+  return dq_impl("fa_bwd_dq", q, k, v, o, dout, lse, dq, delta, B, H, S_q, S_k, D, dtype, causal, scale, &x, stream);
 }
-
-int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
-              float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, void* stream) {
-  return fa_bwd_dq_strided(q, nullptr, k, nullptr, v, nullptr, o, nullptr, dout, nullptr, lse, dq, nullptr, delta, B, H, S_q,
-                           S_k, D, dtype, causal, scale, stream);
-}
-
 int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k, const long long* k_strides,
                        const void* v, const long long* v_strides, const void* dout, const long long* dout_strides,
                        const float* lse, const float* delta, void* dk, const long long* dk_strides, void* dv,
                        const long long* dv_strides, int B, int H, int S_q, int S_k, int D, int dtype, int causal,
                        float scale, void* stream) {
-  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv");
-  if (int rc = check_common("fa_bwd_dkv", B, H, S_q, S_k, D, dtype)) return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
-      misaligned(dk) || misaligned(dv))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv");
-  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
-  if (int rc = make_layout("fa_bwd_dkv", q_strides, H, S_q, D, &p.lq)) return rc;
-  if (int rc = make_layout("fa_bwd_dkv", k_strides, H, S_k, D, &p.lk)) return rc;
-  if (int rc = make_layout("fa_bwd_dkv", v_strides, H, S_k, D, &p.lv)) return rc;
-  if (int rc = make_layout("fa_bwd_dkv", dout_strides, H, S_q, D, &p.ldo)) return rc;
-  if (p.lk.rs != p.lv.rs) return fail(MI355FA_ERR_STRIDE, "%s: K and V must share their sequence stride", "fa_bwd_dkv");
-  set_contiguous_outputs(&p, H, S_q, S_k, D);
-  if (int rc = make_layout("fa_bwd_dkv", dk_strides, H, S_k, D, &p.ldk, B)) return rc;
-  if (int rc = make_layout("fa_bwd_dkv", dv_strides, H, S_k, D, &p.ldv, B)) return rc;
-  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv launch");
-  return 0;
+  mi355fa_opts x = base_opts();
+  x.q_strides = q_strides;
+  x.k_strides = k_strides;
+  x.v_strides = v_strides;
+  x.dout_strides = dout_strides;
+  x.dk_strides = dk_strides;
+  x.dv_strides = dv_strides;
+  return dkv_impl("fa_bwd_dkv", q, k, v, dout, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype, causal, scale, &x, stream);
 }
 
-int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
-               void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
-               void* stream) {
-  return fa_bwd_dkv_strided(q, nullptr, k, nullptr, v, nullptr, dout, nullptr, lse, delta, dk, nullptr, dv, nullptr, B, H, S_q,
-                            S_k, D, dtype, causal, scale, stream);
+// ---- variable-length ("varlen"): packed [total, H, D] tensors + cu_seqlens (include/mi355fa.h) ------------------------
+static mi355fa_opts varlen_opts(const int* cu_q, const int* cu_k, int total_q, int total_k) {
+  mi355fa_opts x = base_opts();
+  x.cu_seqlens_q = cu_q;
+  x.cu_seqlens_k = cu_k;
+  x.total_q = total_q;
+  x.total_k = total_k;
+  return x;
 }
-
-// ---- variable-length ("varlen") entry points: packed [total, H, D] tensors + cu_seqlens (include/mi355fa.h) ----
 int fa_fwd_varlen(const void* q, const void* k, const void* v, void* o, float* lse, const int* cu_seqlens_q,
                   const int* cu_seqlens_k, int batch, int H, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k,
                   int D, int dtype, int causal, float scale, void* stream) {
-  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd_varlen");
-  if (int rc = check_varlen("fa_fwd_varlen", cu_seqlens_q, cu_seqlens_k, batch, H, total_q, total_k, max_seqlen_q,
-                            max_seqlen_k, D, dtype))
-    return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd_varlen");
-  fa::FwdParams p{q, k, v, o, lse, batch, H, max_seqlen_q, max_seqlen_k, scale, 0, g_dbg, 0};
-  p.lq = p.lk = p.lv = p.lo = packed_layout(H, D);
-  p.lse_sb = 0;
-  p.lse_sh = total_q;
-  p.vl = fa::VarLen{cu_seqlens_q, cu_seqlens_k};
-  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_fwd_varlen launch");
-  return 0;
+  if (!cu_seqlens_q || !cu_seqlens_k) return fail(MI355FA_ERR_NULL, "%s: NULL cu_seqlens", "fa_fwd_varlen");
+  const mi355fa_opts x = varlen_opts(cu_seqlens_q, cu_seqlens_k, total_q, total_k);
+  return fwd_impl("fa_fwd_varlen", q, k, v, o, lse, batch, H, max_seqlen_q, max_seqlen_k, D, dtype, causal, scale, &x, stream);
 }
-
-static void fill_varlen_bwd(fa::BwdParams* p, const int* cu_q, const int* cu_k, int H, int total_q, int D) {
-  p->lq = p->lk = p->lv = p->ldo = p->lo = p->ldq = p->ldk = p->ldv = packed_layout(H, D);
-  p->lse_sb = 0;
-  p->lse_sh = total_q;
-  p->vl = fa::VarLen{cu_q, cu_k};
-}
-
 int fa_bwd_dq_varlen(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
                      float* delta, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
                      int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
                      void* stream) {
-  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq_varlen");
-  if (int rc = check_varlen("fa_bwd_dq_varlen", cu_seqlens_q, cu_seqlens_k, batch, H, total_q, total_k, max_seqlen_q,
-                            max_seqlen_k, D, dtype))
-    return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
-      misaligned(dq) || misaligned(delta))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq_varlen");
-  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, batch, H, max_seqlen_q, max_seqlen_k, scale, 0, g_dbg, 0};
-  fill_varlen_bwd(&p, cu_seqlens_q, cu_seqlens_k, H, total_q, D);
-  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq_varlen launch");
-  return 0;
+  if (!cu_seqlens_q || !cu_seqlens_k) return fail(MI355FA_ERR_NULL, "%s: NULL cu_seqlens", "fa_bwd_dq_varlen");
+  const mi355fa_opts x = varlen_opts(cu_seqlens_q, cu_seqlens_k, total_q, total_k);
+  return dq_impl("fa_bwd_dq_varlen", q, k, v, o, dout, lse, dq, delta, batch, H, max_seqlen_q, max_seqlen_k, D, dtype, causal,
+                 scale, &x, stream);
 }
-
 int fa_bwd_dkv_varlen(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                       void* dk, void* dv, const int* cu_seqlens_q, const int* cu_seqlens_k, int batch, int H, int total_q,
                       int total_k, int max_seqlen_q, int max_seqlen_k, int D, int dtype, int causal, float scale,
                       void* stream) {
-  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv_varlen");
-  if (int rc = check_varlen("fa_bwd_dkv_varlen", cu_seqlens_q, cu_seqlens_k, batch, H, total_q, total_k, max_seqlen_q,
-                            max_seqlen_k, D, dtype))
-    return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
-      misaligned(dk) || misaligned(dv))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv_varlen");
-  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, batch, H, max_seqlen_q, max_seqlen_k, scale, 0, g_dbg, 0};
-  fill_varlen_bwd(&p, cu_seqlens_q, cu_seqlens_k, H, total_q, D);
-  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv_varlen launch");
-  return 0;
+  if (!cu_seqlens_q || !cu_seqlens_k) return fail(MI355FA_ERR_NULL, "%s: NULL cu_seqlens", "fa_bwd_dkv_varlen");
+  const mi355fa_opts x = varlen_opts(cu_seqlens_q, cu_seqlens_k, total_q, total_k);
+  return dkv_impl("fa_bwd_dkv_varlen", q, k, v, dout, lse, delta, dk, dv, batch, H, max_seqlen_q, max_seqlen_k, D, dtype,
+                  causal, scale, &x, stream);
 }
 
-// ---- attention dropout (include/mi355fa.h, fa_*_dropout): contiguous [B, H, S, D] tensors as fa_fwd / fa_bwd_* ----
-static int make_dropout(const char* fn, float p_drop, unsigned long long seed, unsigned long long offset,
-                        fa::DropoutParams* out) {
-  if (!(p_drop >= 0.f) || p_drop >= 1.f) return fail(MI355FA_ERR_SHAPE, "%s: dropout probability must be in [0, 1)", fn);
-  unsigned thresh = (unsigned)(p_drop * 256.f + 0.5f);   // p is quantised to multiples of 1/256
-  if (thresh > 255u) thresh = 255u;
-  out->thresh = thresh;
-  out->seed_lo = (unsigned)seed;
-  out->seed_hi = (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32);
-  out->offset = (unsigned)offset;
-  out->rp = 256.f / (256.f - (float)thresh);
-  return 0;
-}
-
+// ---- attention dropout (include/mi355fa.h): contiguous [B, H, S, D] tensors as fa_fwd / fa_bwd_* ----------------------
 float fa_dropout_keep_scale(float p_drop) {   // 1 / (1 - p) for the quantised p the kernels use
   fa::DropoutParams d;
   if (make_dropout("fa_dropout_keep_scale", p_drop, 0, 0, &d)) return 0.f;
   return d.rp;
 }
-
+static mi355fa_opts dropout_opts(float p_drop, unsigned long long seed, unsigned long long offset) {
+  mi355fa_opts x = base_opts();
+  x.p_drop = p_drop;
+  x.seed = seed;
+  x.offset = offset;
+  return x;
+}
 int fa_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
                    int dtype, int causal, float scale, float p_drop, unsigned long long seed, unsigned long long offset,
                    void* stream) {
-  if (!q || !k || !v || !o || !lse) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_fwd_dropout");
-  if (int rc = check_common("fa_fwd_dropout", B, H, S_q, S_k, D, dtype)) return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(lse))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_fwd_dropout");
-  fa::FwdParams p{q, k, v, o, lse, B, H, S_q, S_k, scale, 0, g_dbg, 0};
-  p.lq = p.lo = fa::contiguous_layout(H, S_q, D);
-  p.lk = p.lv = fa::contiguous_layout(H, S_k, D);
-  p.lse_sb = (long long)H * S_q;
-  p.lse_sh = S_q;
-  if (int rc = make_dropout("fa_fwd_dropout", p_drop, seed, offset, &p.drop)) return rc;
-  hipError_t e = fa::launch_fwd(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_fwd_dropout launch");
-  return 0;
+  const mi355fa_opts x = dropout_opts(p_drop, seed, offset);
+  return fwd_impl("fa_fwd_dropout", q, k, v, o, lse, B, H, S_q, S_k, D, dtype, causal, scale, &x, stream);
 }
-
 int fa_bwd_dq_dropout(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
                       float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale, float p_drop,
                       unsigned long long seed, unsigned long long offset, void* stream) {
-  if (!q || !k || !v || !o || !dout || !lse || !dq || !delta) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dq_dropout");
-  if (int rc = check_common("fa_bwd_dq_dropout", B, H, S_q, S_k, D, dtype)) return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
-      misaligned(dq) || misaligned(delta))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dq_dropout");
-  fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
-  p.lq = p.ldo = fa::contiguous_layout(H, S_q, D);
-  p.lk = p.lv = fa::contiguous_layout(H, S_k, D);
-  set_contiguous_outputs(&p, H, S_q, S_k, D);
-  if (int rc = make_dropout("fa_bwd_dq_dropout", p_drop, seed, offset, &p.drop)) return rc;
-  hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dq_dropout launch");
-  return 0;
+  const mi355fa_opts x = dropout_opts(p_drop, seed, offset);
+  return dq_impl("fa_bwd_dq_dropout", q, k, v, o, dout, lse, dq, delta, B, H, S_q, S_k, D, dtype, causal, scale, &x, stream);
 }
-
 int fa_bwd_dkv_dropout(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                        void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
                        float p_drop, unsigned long long seed, unsigned long long offset, void* stream) {
-  if (!q || !k || !v || !dout || !lse || !delta || !dk || !dv) return fail(MI355FA_ERR_NULL, "%s: NULL pointer", "fa_bwd_dkv_dropout");
-  if (int rc = check_common("fa_bwd_dkv_dropout", B, H, S_q, S_k, D, dtype)) return rc;
-  if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
-      misaligned(dk) || misaligned(dv))
-    return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", "fa_bwd_dkv_dropout");
-  fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
-  p.lq = p.ldo = fa::contiguous_layout(H, S_q, D);
-  p.lk = p.lv = fa::contiguous_layout(H, S_k, D);
-  set_contiguous_outputs(&p, H, S_q, S_k, D);
-  if (int rc = make_dropout("fa_bwd_dkv_dropout", p_drop, seed, offset, &p.drop)) return rc;
-  hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "fa_bwd_dkv_dropout launch");
-  return 0;
+  const mi355fa_opts x = dropout_opts(p_drop, seed, offset);
+  return dkv_impl("fa_bwd_dkv_dropout", q, k, v, dout, lse, delta, dk, dv, B, H, S_q, S_k, D, dtype, causal, scale, &x, stream);
 }
 
 }  // extern "C"

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
       u32x4 mine = {0, 0, 0, 0};
       if constexpr (DROP) {
         const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
-        mine = dropout_patch(dr, ((qb0 + 4 * h) >> 2) + 2 * (r & 3), (kw0 + r) >> 2, bh);
+        mine = dropout_patch(dr, ((qb0 + 4 * h) >> 2) + 2 * (r & 3), (kw0 + r) >> 2, b_ * p.H + h_);
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
       u32x4 mine = {0, 0, 0, 0};
       if constexpr (DROP) {
         const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
-        mine = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), bh);
+        mine = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), b_ * p.H + h_);
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {

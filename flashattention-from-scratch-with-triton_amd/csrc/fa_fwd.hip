@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
       const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
 #pragma unroll
       for (int b = 0; b < 2; ++b)
-        if (!(MASKED && !use[b])) mine[b] = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), bh);
+        if (!(MASKED && !use[b])) mine[b] = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), b_ * p.H + h_);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {

@@ -103,9 +103,21 @@ void* current_stream(const Tensor& t) {
   return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
 
+// mi355fa_opts for the general entry points (fa_*_ex): zeroed, sized, with the caller's dropout triple
+mi355fa_opts make_opts(double p_drop, int64_t seed, int64_t offset) {
+  FA_ASSERT(p_drop >= 0.0 && p_drop < 1.0, "dropout_p must be in [0, 1)");
+  mi355fa_opts x{};
+  x.size = sizeof(mi355fa_opts);
+  x.p_drop = (float)p_drop;
+  x.seed = (unsigned long long)seed;
+  x.offset = (unsigned long long)offset;
+  return x;
+}
+
 // flash_attention_forward (M:14-60): allocate O / LSE, enqueue.  Inputs: contiguous or strided_ok views, K and V sharing
-// their sequence stride.
-std::tuple<Tensor, Tensor> forward_launch(const Tensor& Q, const Tensor& K, const Tensor& V, bool causal) {
+// their sequence stride.  dropout_p > 0: attention dropout with the Philox mask of (seed, offset) (include/mi355fa.h).
+std::tuple<Tensor, Tensor> forward_launch(const Tensor& Q, const Tensor& K, const Tensor& V, bool causal, double p_drop,
+                                          int64_t seed, int64_t offset) {
   check_qkv(Q, K, V);
   FA_ASSERT(Q.is_cuda(), "Q, K, V must be device tensors");
   const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
@@ -114,17 +126,22 @@ std::tuple<Tensor, Tensor> forward_launch(const Tensor& Q, const Tensor& K, cons
   Tensor O = out_like(Q);
   Tensor LSE = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
   Strides3 sq(Q), sk(K), sv(V), so(O);
-  check_rc(fa_fwd_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(), so.ptr,
-                          (float*)LSE.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
-                          (float)(1.0 / std::sqrt((double)D)), current_stream(Q)),
+  mi355fa_opts x = make_opts(p_drop, seed, offset);
+  x.q_strides = sq.ptr;
+  x.k_strides = sk.ptr;
+  x.v_strides = sv.ptr;
+  x.o_strides = so.ptr;
+  check_rc(fa_fwd_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), (float*)LSE.data_ptr(), (int)B, (int)H, (int)Sq,
+                     (int)Sk, (int)D, dt, causal ? 1 : 0, (float)(1.0 / std::sqrt((double)D)), &x, current_stream(Q)),
            "fa_fwd");
   return {O, LSE};
 }
 
 // flash_attention_backward (M:62-128): allocate dQ / dK / dV / delta, enqueue dQ (+delta) then dK/dV on the same stream
-// (the dK/dV kernel reads the delta the dQ kernel wrote, K:376).
+// (the dK/dV kernel reads the delta the dQ kernel wrote, K:376).  Dropout: the triple the forward was given.
 std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& O_,
-                                                   const Tensor& dO, const Tensor& LSE, bool causal) {
+                                                   const Tensor& dO, const Tensor& LSE, bool causal, double p_drop,
+                                                   int64_t seed, int64_t offset) {
   check_qkv(Q, K, V);
   FA_ASSERT(Q.is_cuda(), "Q, K, V must be device tensors");
   FA_ASSERT(O_.sizes() == Q.sizes() && dO.sizes() == Q.sizes(), "O and dO must have Q's shape");
@@ -155,15 +172,24 @@ std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor
   }
   Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
   Strides3 sq(Q), sk(K), sv(V), so(O), sdo(dO), sdq(dQ), sdk(dK), sdv(dV);
+  mi355fa_opts x = make_opts(p_drop, seed, offset);
+  x.q_strides = sq.ptr;
+  x.k_strides = sk.ptr;
+  x.v_strides = sv.ptr;
+  x.o_strides = so.ptr;
+  x.dout_strides = sdo.ptr;
+  x.dq_strides = sdq.ptr;
+  x.dk_strides = sdk.ptr;
+  x.dv_strides = sdv.ptr;
   void* st = current_stream(Q);
   const float scale = (float)(1.0 / std::sqrt((double)D));
-  check_rc(fa_bwd_dq_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, O.data_ptr(), so.ptr,
-                             dO.data_ptr(), sdo.ptr, (const float*)LSE.data_ptr(), dQ.data_ptr(), sdq.ptr,
-                             (float*)delta.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
+  check_rc(fa_bwd_dq_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                        dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
+                        scale, &x, st),
            "fa_bwd_dq");
-  check_rc(fa_bwd_dkv_strided(Q.data_ptr(), sq.ptr, K.data_ptr(), sk.ptr, V.data_ptr(), sv.ptr, dO.data_ptr(), sdo.ptr,
-                              (const float*)LSE.data_ptr(), (const float*)delta.data_ptr(), dK.data_ptr(), sdk.ptr,
-                              dV.data_ptr(), sdv.ptr, (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0, scale, st),
+  check_rc(fa_bwd_dkv_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                         (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D,
+                         dt, causal ? 1 : 0, scale, &x, st),
            "fa_bwd_dkv");
   return {dQ, dK, dV};
 }
@@ -182,7 +208,7 @@ class FlashAttnFn : public torch::autograd::Function<FlashAttnFn> {
       K_ = K_.contiguous();
       V_ = V_.contiguous();
     }
-    auto out = forward_launch(Q_, K_, V_, is_causal);
+    auto out = forward_launch(Q_, K_, V_, is_causal, 0.0, 0, 0);
     ctx->save_for_backward({Q_, K_, V_, std::get<0>(out), std::get<1>(out)});
     ctx->saved_data["is_causal"] = is_causal;
     return std::get<0>(out);
@@ -191,7 +217,7 @@ class FlashAttnFn : public torch::autograd::Function<FlashAttnFn> {
     auto s = ctx->get_saved_variables();
     const bool causal = ctx->saved_data["is_causal"].toBool();
     Tensor dO = in_place(grads[0]);
-    auto g = backward_launch(s[0], s[1], s[2], s[3], dO, s[4], causal);
+    auto g = backward_launch(s[0], s[1], s[2], s[3], dO, s[4], causal, 0.0, 0, 0);
     return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor()};
   }
 };
@@ -219,24 +245,30 @@ Tensor packed(const Tensor& t) {  // the varlen kernels read packed rows only: c
 }
 
 std::tuple<Tensor, Tensor> varlen_forward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, const Tensor& cu_q,
-                                                 const Tensor& cu_k, int64_t max_q, int64_t max_k, bool causal) {
+                                                 const Tensor& cu_k, int64_t max_q, int64_t max_k, bool causal, double p_drop,
+                                                 int64_t seed, int64_t offset) {
   check_varlen(Q_, K_, V_, cu_q, cu_k);
   Tensor Q = packed(Q_), K = packed(K_), V = packed(V_);
   const int64_t Tq = Q.size(0), Tk = K.size(0), H = Q.size(1), D = Q.size(2), B = cu_q.numel() - 1;
   c10::OptionalDeviceGuard guard(Q.device());
   Tensor O = torch::empty({Tq, H, D}, Q.options());
   Tensor LSE = torch::empty({H, Tq}, Q.options().dtype(at::kFloat));
-  check_rc(fa_fwd_varlen(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), (float*)LSE.data_ptr(),
-                         (const int*)cu_q.data_ptr(), (const int*)cu_k.data_ptr(), (int)B, (int)H, (int)Tq, (int)Tk, (int)max_q,
-                         (int)max_k, (int)D, dtype_code(Q), causal ? 1 : 0, (float)(1.0 / std::sqrt((double)D)),
-                         current_stream(Q)),
+  mi355fa_opts x = make_opts(p_drop, seed, offset);
+  x.cu_seqlens_q = (const int*)cu_q.data_ptr();
+  x.cu_seqlens_k = (const int*)cu_k.data_ptr();
+  x.total_q = (int)Tq;
+  x.total_k = (int)Tk;
+  check_rc(fa_fwd_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), (float*)LSE.data_ptr(), (int)B, (int)H, (int)max_q,
+                     (int)max_k, (int)D, dtype_code(Q), causal ? 1 : 0, (float)(1.0 / std::sqrt((double)D)), &x,
+                     current_stream(Q)),
            "fa_fwd_varlen");
   return {O, LSE};
 }
 
 std::tuple<Tensor, Tensor, Tensor> varlen_backward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, const Tensor& O_,
                                                           const Tensor& dO_, const Tensor& LSE, const Tensor& cu_q,
-                                                          const Tensor& cu_k, int64_t max_q, int64_t max_k, bool causal) {
+                                                          const Tensor& cu_k, int64_t max_q, int64_t max_k, bool causal,
+                                                          double p_drop, int64_t seed, int64_t offset) {
   check_varlen(Q_, K_, V_, cu_q, cu_k);
   FA_ASSERT(O_.sizes() == Q_.sizes() && dO_.sizes() == Q_.sizes(), "O and dO must have Q's shape");
   FA_ASSERT(LSE.dim() == 2 && LSE.size(0) == Q_.size(1) && LSE.size(1) == Q_.size(0) && LSE.scalar_type() == at::kFloat &&
@@ -252,14 +284,18 @@ std::tuple<Tensor, Tensor, Tensor> varlen_backward_launch(const Tensor& Q_, cons
   void* st = current_stream(Q);
   const float scale = (float)(1.0 / std::sqrt((double)D));
   const int dt = dtype_code(Q);
-  check_rc(fa_bwd_dq_varlen(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
-                            dQ.data_ptr(), (float*)delta.data_ptr(), (const int*)cu_q.data_ptr(), (const int*)cu_k.data_ptr(),
-                            (int)B, (int)H, (int)Tq, (int)Tk, (int)max_q, (int)max_k, (int)D, dt, causal ? 1 : 0, scale, st),
+  mi355fa_opts x = make_opts(p_drop, seed, offset);
+  x.cu_seqlens_q = (const int*)cu_q.data_ptr();
+  x.cu_seqlens_k = (const int*)cu_k.data_ptr();
+  x.total_q = (int)Tq;
+  x.total_k = (int)Tk;
+  check_rc(fa_bwd_dq_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                        dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H, (int)max_q, (int)max_k, (int)D, dt,
+                        causal ? 1 : 0, scale, &x, st),
            "fa_bwd_dq_varlen");
-  check_rc(fa_bwd_dkv_varlen(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
-                             (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (const int*)cu_q.data_ptr(),
-                             (const int*)cu_k.data_ptr(), (int)B, (int)H, (int)Tq, (int)Tk, (int)max_q, (int)max_k, (int)D, dt,
-                             causal ? 1 : 0, scale, st),
+  check_rc(fa_bwd_dkv_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
+                         (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (int)B, (int)H, (int)max_q, (int)max_k,
+                         (int)D, dt, causal ? 1 : 0, scale, &x, st),
            "fa_bwd_dkv_varlen");
   return {dQ, dK, dV};
 }
@@ -267,88 +303,50 @@ std::tuple<Tensor, Tensor, Tensor> varlen_backward_launch(const Tensor& Q_, cons
 class FlashAttnVarlenFn : public torch::autograd::Function<FlashAttnVarlenFn> {
  public:
   static Tensor forward(AutogradContext* ctx, const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& cu_q,
-                        const Tensor& cu_k, int64_t max_q, int64_t max_k, bool is_causal) {
+                        const Tensor& cu_k, int64_t max_q, int64_t max_k, bool is_causal, double p_drop, int64_t seed,
+                        int64_t offset) {
     FA_ASSERT(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kBFloat16, "dtype must be float16 or bfloat16");
     Tensor Q_ = packed(Q), K_ = packed(K), V_ = packed(V);
-    auto out = varlen_forward_launch(Q_, K_, V_, cu_q, cu_k, max_q, max_k, is_causal);
+    auto out = varlen_forward_launch(Q_, K_, V_, cu_q, cu_k, max_q, max_k, is_causal, p_drop, seed, offset);
     ctx->save_for_backward({Q_, K_, V_, std::get<0>(out), std::get<1>(out), cu_q, cu_k});
     ctx->saved_data["is_causal"] = is_causal;
     ctx->saved_data["max_q"] = max_q;
     ctx->saved_data["max_k"] = max_k;
+    ctx->saved_data["p"] = p_drop;
+    ctx->saved_data["seed"] = seed;
+    ctx->saved_data["offset"] = offset;
     return std::get<0>(out);
   }
   static tensor_list backward(AutogradContext* ctx, tensor_list grads) {
     auto s = ctx->get_saved_variables();
     auto g = varlen_backward_launch(s[0], s[1], s[2], s[3], grads[0], s[4], s[5], s[6], ctx->saved_data["max_q"].toInt(),
-                                    ctx->saved_data["max_k"].toInt(), ctx->saved_data["is_causal"].toBool());
-    return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+                                    ctx->saved_data["max_k"].toInt(), ctx->saved_data["is_causal"].toBool(),
+                                    ctx->saved_data["p"].toDouble(), ctx->saved_data["seed"].toInt(),
+                                    ctx->saved_data["offset"].toInt());
+    return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor()};
   }
 };
 
 Tensor flash_attention_varlen(const Tensor& Q, const Tensor& K, const Tensor& V, const Tensor& cu_q, const Tensor& cu_k,
-                              int64_t max_q, int64_t max_k, bool is_causal) {
-  return FlashAttnVarlenFn::apply(Q, K, V, cu_q, cu_k, max_q, max_k, is_causal);
+                              int64_t max_q, int64_t max_k, bool is_causal, double p_drop, int64_t seed, int64_t offset) {
+  return FlashAttnVarlenFn::apply(Q, K, V, cu_q, cu_k, max_q, max_k, is_causal, p_drop, seed, offset);
 }
 
-// ---- attention dropout (include/mi355fa.h, fa_*_dropout): contiguous [B, H, S, D] tensors --------------------------
-Tensor dense(const Tensor& t) {
-  return (t.is_contiguous() && reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0) ? t : t.clone(at::MemoryFormat::Contiguous);
-}
-
-std::tuple<Tensor, Tensor> dropout_forward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, bool causal, double p_drop,
-                                                  int64_t seed, int64_t offset) {
-  check_qkv(Q_, K_, V_);
-  FA_ASSERT(Q_.is_cuda(), "Q, K, V must be device tensors");
-  FA_ASSERT(p_drop >= 0.0 && p_drop < 1.0, "dropout_p must be in [0, 1)");
-  Tensor Q = dense(Q_), K = dense(K_), V = dense(V_);
-  const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
-  c10::OptionalDeviceGuard guard(Q.device());
-  Tensor O = torch::empty({B, H, Sq, D}, Q.options());
-  Tensor LSE = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
-  check_rc(fa_fwd_dropout(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), (float*)LSE.data_ptr(), (int)B, (int)H, (int)Sq,
-                          (int)Sk, (int)D, dtype_code(Q), causal ? 1 : 0, (float)(1.0 / std::sqrt((double)D)), (float)p_drop,
-                          (unsigned long long)seed, (unsigned long long)offset, current_stream(Q)),
-           "fa_fwd_dropout");
-  return {O, LSE};
-}
-
-std::tuple<Tensor, Tensor, Tensor> dropout_backward_launch(const Tensor& Q_, const Tensor& K_, const Tensor& V_, const Tensor& O_,
-                                                           const Tensor& dO_, const Tensor& LSE, bool causal, double p_drop,
-                                                           int64_t seed, int64_t offset) {
-  check_qkv(Q_, K_, V_);
-  FA_ASSERT(Q_.is_cuda(), "Q, K, V must be device tensors");
-  FA_ASSERT(O_.sizes() == Q_.sizes() && dO_.sizes() == Q_.sizes(), "O and dO must have Q's shape");
-  FA_ASSERT(LSE.dim() == 3 && LSE.scalar_type() == at::kFloat && LSE.is_contiguous() && LSE.device() == Q_.device(),
-            "LSE must be contiguous float32 [B, H, S_q]");
-  Tensor Q = dense(Q_), K = dense(K_), V = dense(V_), O = dense(O_), dO = dense(dO_);
-  const int64_t B = Q.size(0), H = Q.size(1), Sq = Q.size(2), D = Q.size(3), Sk = K.size(2);
-  c10::OptionalDeviceGuard guard(Q.device());
-  Tensor dQ = torch::empty({B, H, Sq, D}, Q.options());
-  Tensor g = torch::empty({2, B, H, Sk, D}, Q.options());
-  Tensor dK = g.select(0, 0), dV = g.select(0, 1);
-  Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
-  void* st = current_stream(Q);
-  const float scale = (float)(1.0 / std::sqrt((double)D));
-  const int dt = dtype_code(Q);
-  check_rc(fa_bwd_dq_dropout(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
-                             dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
-                             scale, (float)p_drop, (unsigned long long)seed, (unsigned long long)offset, st),
-           "fa_bwd_dq_dropout");
-  check_rc(fa_bwd_dkv_dropout(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
-                              (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D,
-                              dt, causal ? 1 : 0, scale, (float)p_drop, (unsigned long long)seed, (unsigned long long)offset, st),
-           "fa_bwd_dkv_dropout");
-  return {dQ, dK, dV};
-}
-
+// ---- attention dropout (include/mi355fa.h): the plain launchers with a (p, seed, offset) triple; views read in place ----
 class FlashAttnDropoutFn : public torch::autograd::Function<FlashAttnDropoutFn> {
  public:
   static Tensor forward(AutogradContext* ctx, const Tensor& Q, const Tensor& K, const Tensor& V, bool is_causal, double p_drop,
                         int64_t seed, int64_t offset) {
     FA_ASSERT(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kBFloat16, "dtype must be float16 or bfloat16");
     FA_ASSERT(Q.dim() == 4 && (Q.size(3) == 64 || Q.size(3) == 128), "head dim must be 64 or 128");
-    Tensor Q_ = dense(Q), K_ = dense(K), V_ = dense(V);
-    auto out = dropout_forward_launch(Q_, K_, V_, is_causal, p_drop, seed, offset);
+    check_qkv(Q, K, V);
+    Tensor Q_ = in_place(Q), K_ = in_place(K), V_ = in_place(V);
+    if (K_.size(2) > 1 && K_.stride(2) != V_.stride(2)) {  // the kernels use one row stride for the K/V pair
+      K_ = K_.contiguous();
+      V_ = V_.contiguous();
+    }
+    auto out = forward_launch(Q_, K_, V_, is_causal, p_drop, seed, offset);
     ctx->save_for_backward({Q_, K_, V_, std::get<0>(out), std::get<1>(out)});
     ctx->saved_data["is_causal"] = is_causal;
     ctx->saved_data["p"] = p_drop;
@@ -358,9 +356,9 @@ class FlashAttnDropoutFn : public torch::autograd::Function<FlashAttnDropoutFn> 
   }
   static tensor_list backward(AutogradContext* ctx, tensor_list grads) {
     auto s = ctx->get_saved_variables();
-    auto g = dropout_backward_launch(s[0], s[1], s[2], s[3], grads[0], s[4], ctx->saved_data["is_causal"].toBool(),
-                                     ctx->saved_data["p"].toDouble(), ctx->saved_data["seed"].toInt(),
-                                     ctx->saved_data["offset"].toInt());
+    auto g = backward_launch(s[0], s[1], s[2], s[3], in_place(grads[0]), s[4], ctx->saved_data["is_causal"].toBool(),
+                             ctx->saved_data["p"].toDouble(), ctx->saved_data["seed"].toInt(),
+                             ctx->saved_data["offset"].toInt());
     return {std::get<0>(g), std::get<1>(g), std::get<2>(g), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
@@ -376,17 +374,27 @@ PYBIND11_MODULE(_mi355fa_torch, m) {
   m.doc() = "C++ launchers and autograd function over libmi355fa.so (see My_FlashAttention_optimized.py)";
   m.def("flash_attention", &flash_attention, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
         pybind11::arg("is_causal") = false);
-  m.def("forward_launch", &forward_launch);
-  m.def("backward_launch", &backward_launch);
+  m.def("forward_launch", &forward_launch, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"), pybind11::arg("is_causal"),
+        pybind11::arg("dropout_p") = 0.0, pybind11::arg("seed") = 0, pybind11::arg("offset") = 0);
+  m.def("backward_launch", &backward_launch, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"), pybind11::arg("O"),
+        pybind11::arg("dO"), pybind11::arg("LSE"), pybind11::arg("is_causal"), pybind11::arg("dropout_p") = 0.0,
+        pybind11::arg("seed") = 0, pybind11::arg("offset") = 0);
   m.def("flash_attention_varlen", &flash_attention_varlen, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
         pybind11::arg("cu_seqlens_q"), pybind11::arg("cu_seqlens_k"), pybind11::arg("max_seqlen_q"),
-        pybind11::arg("max_seqlen_k"), pybind11::arg("is_causal") = false);
-  m.def("varlen_forward_launch", &varlen_forward_launch);
-  m.def("varlen_backward_launch", &varlen_backward_launch);
+        pybind11::arg("max_seqlen_k"), pybind11::arg("is_causal") = false, pybind11::arg("dropout_p") = 0.0,
+        pybind11::arg("seed") = 0, pybind11::arg("offset") = 0);
+  m.def("varlen_forward_launch", &varlen_forward_launch, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
+        pybind11::arg("cu_seqlens_q"), pybind11::arg("cu_seqlens_k"), pybind11::arg("max_seqlen_q"),
+        pybind11::arg("max_seqlen_k"), pybind11::arg("is_causal"), pybind11::arg("dropout_p") = 0.0, pybind11::arg("seed") = 0,
+        pybind11::arg("offset") = 0);
+  m.def("varlen_backward_launch", &varlen_backward_launch, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
+        pybind11::arg("O"), pybind11::arg("dO"), pybind11::arg("LSE"), pybind11::arg("cu_seqlens_q"),
+        pybind11::arg("cu_seqlens_k"), pybind11::arg("max_seqlen_q"), pybind11::arg("max_seqlen_k"), pybind11::arg("is_causal"),
+        pybind11::arg("dropout_p") = 0.0, pybind11::arg("seed") = 0, pybind11::arg("offset") = 0);
   m.def("flash_attention_dropout", &flash_attention_dropout, pybind11::arg("Q"), pybind11::arg("K"), pybind11::arg("V"),
         pybind11::arg("is_causal"), pybind11::arg("dropout_p"), pybind11::arg("seed"), pybind11::arg("offset") = 0);
-  m.def("dropout_forward_launch", &dropout_forward_launch);
-  m.def("dropout_backward_launch", &dropout_backward_launch);
+  m.def("dropout_forward_launch", &forward_launch);    // the general launchers under their round-2 names
+  m.def("dropout_backward_launch", &backward_launch);
   m.def("dropout_keep_scale", [](double p) { return (double)fa_dropout_keep_scale((float)p); });
   m.def("abi_version", []() { return fa_abi_version(); });
 }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355FA_ABI_VERSION 5
+#define MI355FA_ABI_VERSION 6
 
 /* dtype codes */
 #define MI355FA_FP16 0
@@ -146,6 +146,35 @@ int fa_bwd_dq_dropout(const void* q, const void* k, const void* v, const void* o
 int fa_bwd_dkv_dropout(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                        void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
                        float p_drop, unsigned long long seed, unsigned long long offset, void* stream);
+
+/* ---- General form: strides, variable-length batches and dropout in any combination ----------------------------------
+ * Every entry point above is this call with some fields of mi355fa_opts set.  Zero-initialise the struct, set
+ * `size = sizeof(mi355fa_opts)` (checked: a library built for another layout refuses the call) and fill what applies:
+ *   - *_strides: element strides {batch, head, seq} per tensor as for the *_strided functions (NULL = contiguous);
+ *     o_strides describes O for both fa_fwd_ex (output) and fa_bwd_dq_ex (input).  Not allowed together with cu_seqlens.
+ *   - cu_seqlens_q / cu_seqlens_k (both or neither) + total_q / total_k: packed [total, H, D] tensors as for the *_varlen
+ *     functions; then B = number of sequences and S_q / S_k = max_seqlen_q / max_seqlen_k.
+ *   - p_drop / seed / offset: attention dropout as for the *_dropout functions.  With cu_seqlens the Philox counter uses
+ *     the position INSIDE each sequence and slice index (sequence * H + head), so a packed batch drops exactly the weights
+ *     the same sequences would lose in a padded [B, H, S, D] launch with the same (seed, offset).
+ * opts == NULL is the plain launch (fa_fwd / fa_bwd_dq / fa_bwd_dkv). */
+typedef struct mi355fa_opts {
+  unsigned size;
+  const long long *q_strides, *k_strides, *v_strides, *o_strides, *dout_strides, *dq_strides, *dk_strides, *dv_strides;
+  const int *cu_seqlens_q, *cu_seqlens_k;
+  int total_q, total_k;
+  float p_drop;
+  unsigned long long seed, offset;
+} mi355fa_opts;
+
+int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
+              int dtype, int causal, float scale, const mi355fa_opts* opts, void* stream);
+int fa_bwd_dq_ex(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                 float* delta, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+                 const mi355fa_opts* opts, void* stream);
+int fa_bwd_dkv_ex(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                  void* dk, void* dv, int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
+                  const mi355fa_opts* opts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -357,3 +357,30 @@ def attention_dropout_fp64(Q, K, V, dO, is_causal, keep, rp):
     O.backward(do)
     return {"O": O.detach(), "LSE": lse.detach(), "dQ": q.grad, "dK": k.grad, "dV": v.grad,
             "delta": (do * O.detach()).sum(-1)}
+
+
+def attention_varlen_dropout_fp64(Q, K, V, dO, cu_q, cu_k, causal, p_drop, seed, offset=0):
+    """Variable-length attention WITH dropout (both extensions of Phase_6.md composed; include/mi355fa.h, mi355fa_opts):
+    sequence b of the packed batch uses the keep mask of batch index b of a padded launch -- Philox counter
+    {q >> 2, k >> 2, b*H + h, offset} with q, k counted inside the sequence.  Returns packed O, dQ, dK, dV (fp64)."""
+    cu_q = [int(x) for x in cu_q]
+    cu_k = [int(x) for x in cu_k]
+    nb = len(cu_q) - 1
+    Tq, H, D = Q.shape
+    mq = max(cu_q[b + 1] - cu_q[b] for b in range(nb))
+    mk = max(cu_k[b + 1] - cu_k[b] for b in range(nb))
+    keep, rp = dropout_keep_mask(nb, H, mq, mk, p_drop, seed, offset)
+    out = {"O": torch.zeros(Q.shape, dtype=torch.float64), "dQ": torch.zeros(Q.shape, dtype=torch.float64),
+           "dK": torch.zeros(K.shape, dtype=torch.float64), "dV": torch.zeros(V.shape, dtype=torch.float64)}
+    for b in range(nb):
+        q0, q1, k0, k1 = cu_q[b], cu_q[b + 1], cu_k[b], cu_k[b + 1]
+        if q1 == q0 or k1 == k0:
+            continue
+        sl = lambda t, a, e: t[a:e].transpose(0, 1).unsqueeze(0)      # [1, H, S, D]
+        g = attention_dropout_fp64(sl(Q, q0, q1), sl(K, k0, k1), sl(V, k0, k1), sl(dO, q0, q1), causal,
+                                   keep[b:b + 1, :, :q1 - q0, :k1 - k0], rp)
+        out["O"][q0:q1] = g["O"][0].transpose(0, 1)
+        out["dQ"][q0:q1] = g["dQ"][0].transpose(0, 1)
+        out["dK"][k0:k1] = g["dK"][0].transpose(0, 1)
+        out["dV"][k0:k1] = g["dV"][0].transpose(0, 1)
+    return out

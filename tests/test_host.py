@@ -20,10 +20,10 @@ def _header_functions():
 
 
 def test_header_declares_expected_entry_points():
-    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_dropout", "fa_bwd_dkv_strided",
-                                   "fa_bwd_dkv_varlen", "fa_bwd_dq", "fa_bwd_dq_dropout", "fa_bwd_dq_strided",
-                                   "fa_bwd_dq_varlen", "fa_dropout_keep_scale", "fa_fwd", "fa_fwd_dropout", "fa_fwd_strided",
-                                   "fa_fwd_varlen", "fa_last_error", "fa_supported"]
+    assert _header_functions() == ["fa_abi_version", "fa_bwd_dkv", "fa_bwd_dkv_dropout", "fa_bwd_dkv_ex", "fa_bwd_dkv_strided",
+                                   "fa_bwd_dkv_varlen", "fa_bwd_dq", "fa_bwd_dq_dropout", "fa_bwd_dq_ex", "fa_bwd_dq_strided",
+                                   "fa_bwd_dq_varlen", "fa_dropout_keep_scale", "fa_fwd", "fa_fwd_dropout", "fa_fwd_ex",
+                                   "fa_fwd_strided", "fa_fwd_varlen", "fa_last_error", "fa_supported"]
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(raw, name), name
         assert name in fa.SIGNATURES, "python binding misses " + name
-    assert fa.lib.fa_abi_version() == 5
+    assert fa.lib.fa_abi_version() == 6
     assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_torch_binding_loads_and_matches_the_abi():
     import _mi355fa as fa
     import _mi355fa_torch as ext
-    assert ext.abi_version() == fa.ABI_VERSION == 5
+    assert ext.abi_version() == fa.ABI_VERSION == 6
     for name in ("flash_attention", "forward_launch", "backward_launch", "flash_attention_varlen", "varlen_forward_launch",
                  "varlen_backward_launch", "flash_attention_dropout", "dropout_forward_launch", "dropout_backward_launch"):
         assert callable(getattr(ext, name)), name
@@ -84,6 +84,30 @@ def test_argument_errors_are_rejected_before_launch():
     assert b"output" in L.fa_last_error()
     assert L.fa_bwd_dq_strided(p, ok, p, ok, p, ok, p, S3(1024, 0, 128), p, ok, p, p, S3(1024, 0, 128), p, *args) == -6
     assert L.fa_bwd_dkv_strided(p, ok, p, ok, p, ok, p, ok, p, p, p, ok, p, S3(1024, 64, 100), *args) == -6
+
+
+def test_general_entry_points_validate_their_options():
+    """fa_*_ex (include/mi355fa.h): the options struct is size-checked, cu_seqlens come in pairs and exclude strides, the
+    dropout probability is range-checked -- all before anything is launched (no GPU needed)."""
+    import _mi355fa as fa
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    L = fa.lib
+    args = (1, 2, 8, 8, 64, 1, 0, 0.125)
+    bad = fa.Opts.make()
+    bad.size = 4
+    assert L.fa_fwd_ex(p, p, p, p, p, *args, ctypes.byref(bad), None) == -2
+    assert b"size" in L.fa_last_error()
+    one = fa.Opts.make(cu_seqlens_q=p)
+    assert L.fa_fwd_ex(p, p, p, p, p, *args, ctypes.byref(one), None) == -1
+    S3 = ctypes.c_longlong * 3
+    both = fa.Opts.make(cu_seqlens_q=p, cu_seqlens_k=p, total_q=8, total_k=8, q_strides=S3(1024, 64, 128))
+    assert L.fa_bwd_dq_ex(p, p, p, p, p, p, p, p, *args, ctypes.byref(both), None) == -6
+    assert b"packed" in L.fa_last_error()
+    assert L.fa_bwd_dkv_ex(p, p, p, p, p, p, p, p, *args, ctypes.byref(fa.Opts.make(p_drop=1.0)), None) == -2
+    assert b"dropout" in L.fa_last_error()
+    assert L.fa_fwd_ex(None, p, p, p, p, *args, None, None) == -1                 # opts == NULL is the plain launch
+    assert ctypes.sizeof(fa.Opts) == 120                                          # layout of mi355fa_opts on LP64
 
 
 def test_schedule_table_lookup_and_override():
@@ -151,8 +175,9 @@ def test_varlen_argument_errors_are_rejected_before_launch():
     with pytest.raises(AssertionError, match="device tensors"):
         M.flash_attention_varlen(q, q, q, cu, cu, 6, 6, True)
     sig = [(p_.name, p_.default) for p_ in inspect.signature(M.flash_attention_varlen).parameters.values()]
-    assert [n for n, _ in sig] == ["Q", "K", "V", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "is_causal"]
-    assert sig[-1][1] is False
+    assert [n for n, _ in sig] == ["Q", "K", "V", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "is_causal",
+                                   "dropout_p", "seed", "offset"]
+    assert sig[7][1] is False and sig[8][1] == 0.0
 
 
 def test_strided_ok_accepts_bshd_views_and_rejects_the_rest():

@@ -142,3 +142,18 @@ def test_philox4x32_10_known_answers_and_keep_mask_layout():
     assert k0.all()                                     # p = 0 keeps everything
     k2, _ = fo.dropout_keep_mask(2, 3, 37, 50, 0.25, seed=0x123456789abcdef, offset=8)
     assert not torch.equal(keep, k2)                    # a different offset is a different mask
+
+
+def test_varlen_dropout_oracle_equals_the_batched_one_on_equal_lengths():
+    """attention_varlen_dropout_fp64 on a packed batch of equal-length sequences = attention_dropout_fp64 on the same
+    sequences stacked as [B, H, S, D] with the same (seed, offset): sequence b uses the mask of batch index b."""
+    B, H, S, D, p, seed, offset = 3, 2, 37, 16, 0.3, 0x1234ABCD, 7
+    torch.manual_seed(2)
+    Q, K, V, dO = (torch.randn(B, H, S, D, dtype=torch.float64) for _ in range(4))
+    keep, rp = fo.dropout_keep_mask(B, H, S, S, p, seed, offset)
+    want = fo.attention_dropout_fp64(Q, K, V, dO, True, keep, rp)
+    pk = lambda x: x.transpose(1, 2).reshape(B * S, H, D)
+    cu = [S * i for i in range(B + 1)]
+    got = fo.attention_varlen_dropout_fp64(pk(Q), pk(K), pk(V), pk(dO), cu, cu, True, p, seed, offset)
+    for k in ("O", "dQ", "dK", "dV"):
+        assert torch.allclose(got[k], pk(want[k]), rtol=1e-12, atol=1e-12), k
