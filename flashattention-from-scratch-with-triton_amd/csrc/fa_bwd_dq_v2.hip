@@ -124,6 +124,16 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
     for (int db = 0; db < C::DB; ++db) tr_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
 
   const float c2 = p.scale * kLog2e;
+  // FOLD (bf16, fa_common.h / fa_bwd_dq.hip): Q carries c2, the same rounded operand the folded forward kernels used for
+  // LSE, so the recomputed P is consistent with it.  Unlike fa_bwd_dq.hip the chains still start from zero (two query
+  // blocks per wave: starting them from -LSE*log2e / -delta keeps 64 more registers live and spills several hundred).
+  constexpr bool FOLD = T::kFoldScale;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) qf[j][ks] = scale_frag<T>(qf[j][ks], c2);
+  }
   f32x16 dqacc[2][C::DB];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float x = __builtin_fmaf(s[j][i], c2, nl[j]);
+        float x = FOLD ? s[j][i] + nl[j] : __builtin_fmaf(s[j][i], c2, nl[j]);
         if constexpr (MASKED) {
           const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           const bool dead = (CAUSAL && key > qw0 + 32 * j + r) || key >= p.Sk;

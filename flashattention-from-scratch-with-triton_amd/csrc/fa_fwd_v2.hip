@@ -21,7 +21,14 @@
 
 namespace fa {
 
+// A/B hook (as fa_fwd.hip FA_FWD_PRIO): 1 = raise the wave's priority over the MFMA chains of a lazy tile
+#ifndef FA_FWD2_PRIO
+#define FA_FWD2_PRIO 1
+#endif
+#define FA_PRIO2_MFMA(on) do { if (FA_FWD2_PRIO == 1) __builtin_amdgcn_s_setprio(on); } while (0)
+
 constexpr float kDeferLog2V2 = 6.0f;  // see fa_fwd.hip: deferred online-softmax rescale
+constexpr float kLazySumMaxV2 = 8192.0f;  // see fa_fwd.hip: largest partial row sum a lazy tile accepts
 
 struct Fwd2Cfg {
   static constexpr int D = 64;
@@ -111,16 +118,14 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
 #pragma unroll
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + 8 * i + (lane >> 3);
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane & 7) * 16;
+    // dma_pieces (fa_common.h): piece i carries the immediate offset 1024*i, which also moves the global address
+    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane & 7) * 16 - 1024 * i;
   }
-  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {  // buf: compile-time constant at every call site
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
     const int soff = t * C::TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < C::DMA_PER_MAT; ++i) {
-      const int dst = buf * C::TILE_BYTES + (16 * wave + 8 * i) * C::ROWB;
-      dma16(rk, lds_addr_of(smem + dst), dma_src[i], soff);
-      dma16(rv, lds_addr_of(smem + C::V_BASE + dst), dma_src[i], soff);
-    }
+    const int dst0 = buf * C::TILE_BYTES + 16 * wave * C::ROWB;  // this wave's 16 rows = DMA_PER_MAT consecutive KiB
+    dma_pieces<C::DMA_PER_MAT>(rk, lds_addr_of(smem + dst0), dma_src, soff);
+    dma_pieces<C::DMA_PER_MAT>(rv, lds_addr_of(smem + C::V_BASE + dst0), dma_src, soff);
   };
   constexpr int DMA_PER_TILE = 2 * C::DMA_PER_MAT;  // vmcnt units per tile per wave
 
@@ -146,8 +151,18 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     for (int db = 0; db < C::DB; ++db) v_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
 
   const float c2 = p.scale * kLog2e;
-  const float defer_raw = kDeferLog2V2 / c2;
-  float m[2] = {-INFINITY, -INFINITY};
+  // FOLD (bf16, fa_common.h / fa_fwd.hip): Q carries c2, the MFMA delivers scores in log2 units (cs = 1) and a lazy
+  // tile's score chains start from -m, so the exponent argument needs no VALU op at all
+  constexpr bool FOLD = T::kFoldScale;
+  const float cs = FOLD ? 1.0f : c2;  // accumulator units -> log2 units
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) qf[j][ks] = scale_frag<T>(qf[j][ks], c2);
+  }
+  const float defer_raw = kDeferLog2V2 / cs;
+  float m[2] = {-INFINITY, -INFINITY};  // running row max in accumulator units (raw scores, or log2 units if FOLD)
   float l[2] = {0.f, 0.f};
   f32x16 oacc[2][C::DB];
 #pragma unroll
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     const float tm = half_max(__builtin_fmaxf(t0, t1));
     if (__builtin_amdgcn_ballot_w64(tm > m[j] + defer_raw) != 0) {
       const float mn = __builtin_fmaxf(m[j], tm);
-      const float corr = __builtin_amdgcn_exp2f((m[j] - mn) * c2);
+      const float corr = __builtin_amdgcn_exp2f((m[j] - mn) * cs);
       l[j] *= corr;
 #pragma unroll
       for (int db = 0; db < C::DB; ++db)
@@ -201,13 +216,13 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   // p = exp2(s*c2 - m*c2), row-sum into l, round to the 16-bit B fragments
   auto probs = [&](auto jt, f32x16 (&s)[2], vec8 (&pf)[2][2]) __attribute__((always_inline)) {
     constexpr int j = decltype(jt)::value;
-    const float mc = m[j] * c2;
+    const float mc = m[j] * cs;
     float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][i], c2, -mc));
+        const float pe = __builtin_amdgcn_exp2f(FOLD ? s[b][i] - mc : __builtin_fmaf(s[b][i], c2, -mc));
         s[b][i] = pe;
         ls[i & 3] += pe;
       }
@@ -297,7 +312,91 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
       }
     }
   };
-  // masked tile (causal diagonal and/or ragged key tail); rare, so no overlap games
+  // unmasked tile with a LAZY running max (fa_fwd.hip tile_lazy): both query blocks are exponentiated against their
+  // stale row max -- no max reduction, no lane exchange, no rescale test; FOLD: the chains start from -m, so the MFMA
+  // output IS the exponent argument.  A lane's partial row sums bound every p it holds: if none exceeds kLazySumMaxV2
+  // nothing can overflow and the stale max is as good as the true one; otherwise (always the first tile) nothing has been
+  // committed and the caller redoes the tile on the exact path.
+  auto tile_lazy = [&](int buf) __attribute__((always_inline)) -> bool {
+    const FA_LDS char* kt = smem + buf * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + C::V_BASE + buf * C::TILE_BYTES;
+    f32x16 s0[2], s1[2];
+    const float i0 = FOLD ? -m[0] : 0.f, i1 = FOLD ? -m[1] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s0[b][i] = i0;
+        s1[b][i] = i1;
+      }
+    {
+      constexpr int NF = 2 * C::KS;
+      vec8 kfr[NF];
+      auto kread = [&](int f) __attribute__((always_inline)) {
+        kfr[f] = as_vec8<T>(lds_read16(kt + k_off[f % C::KS] + (f / C::KS) * 32 * C::ROWB));
+      };
+      kread(0);
+      kread(1);
+      __builtin_amdgcn_sched_barrier(0);
+      FA_PRIO2_MFMA(1);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) kread(f + 2);
+        s0[f / C::KS] = T::mfma(kfr[f], qf[0][f % C::KS], s0[f / C::KS]);
+        s1[f / C::KS] = T::mfma(kfr[f], qf[1][f % C::KS], s1[f / C::KS]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FA_PRIO2_MFMA(0);
+    }
+    const float mc0 = m[0] * c2, mc1 = m[1] * c2;
+    float la[4] = {0.f, 0.f, 0.f, 0.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p0e = __builtin_amdgcn_exp2f(FOLD ? s0[b][i] : __builtin_fmaf(s0[b][i], c2, -mc0));
+        s0[b][i] = p0e;
+        la[i & 3] += p0e;
+        const float p1e = __builtin_amdgcn_exp2f(FOLD ? s1[b][i] : __builtin_fmaf(s1[b][i], c2, -mc1));
+        s1[b][i] = p1e;
+        lb[i & 3] += p1e;
+      }
+    const float ls0 = (la[0] + la[1]) + (la[2] + la[3]), ls1 = (lb[0] + lb[1]) + (lb[2] + lb[3]);
+    if (__builtin_amdgcn_ballot_w64(!(ls0 <= kLazySumMaxV2) || !(ls1 <= kLazySumMaxV2)) != 0) return false;
+    l[0] += ls0;
+    l[1] += ls1;
+    vec8 p0[2][2], p1[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      p0[b][0] = pack8<T, 0>(s0[b]);
+      p0[b][1] = pack8<T, 1>(s0[b]);
+      p1[b][0] = pack8<T, 0>(s1[b]);
+      p1[b][1] = pack8<T, 1>(s1[b]);
+    }
+    {
+      constexpr int NF = 2 * C::DB * 2;
+      vec8 vfr[NF];
+      auto vread = [&](int f) __attribute__((always_inline)) {
+        const FA_LDS char* base = vt + (f / (2 * C::DB)) * 32 * C::ROWB + (f % 2) * 16 * C::ROWB;
+        const int db = (f / 2) % C::DB;
+        vfr[f] = lds_read_tr_frag<T>(base + v_off[0][db], base + v_off[1][db]);
+      };
+      vread(0);
+      vread(1);
+      FA_PRIO2_MFMA(1);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + 2 < NF) vread(f + 2);
+        const int b = f / (2 * C::DB), db = (f / 2) % C::DB, ks = f % 2;
+        oacc[0][db] = T::mfma(vfr[f], p0[b][ks], oacc[0][db]);
+        oacc[1][db] = T::mfma(vfr[f], p1[b][ks], oacc[1][db]);
+      }
+      FA_PRIO2_MFMA(0);
+    }
+    return true;
+  };
+  // masked tile (causal diagonal and/or ragged key tail) on the exact path.  (Trying the lazy path first, per query
+  // block, measured -0.9 % causal: the extra body and its control-flow joins cost more than the one tile per pass saves.)
   auto tile_masked = [&](int t, int buf) __attribute__((always_inline)) {
     const FA_LDS char* kt = smem + buf * C::TILE_BYTES;
     const FA_LDS char* vt = smem + C::V_BASE + buf * C::TILE_BYTES;
@@ -335,28 +434,14 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  // one ring step on an unmasked tile: tile t lives in buffer BUF, tile t+2 goes to buffer (BUF+2)%3
-  auto step_full = [&](int t, auto buf_tag) __attribute__((always_inline)) {
-    constexpr int BUF = decltype(buf_tag)::value;
-    const bool fetch = t + 2 < ntiles;
-    if (fetch) dma_tile(t + 2, (BUF + 2) % 3);
-    FA_STAMP(0);  // DMA issue
-    tile_full(BUF);
-    FA_STAMP(4);  // P V MFMAs
-    ring_sync(fetch);
-    FA_STAMP(5);  // vmcnt + barrier
-  };
   // the remaining steps of the workgroup: this wave's masked tile(s), then tiles it only helps stream
-  auto step_tail = [&](int t) __attribute__((always_inline)) {
+  auto step_tail = [&](int t, bool prefetched) __attribute__((always_inline)) {
     const int buf = t % 3;
     const bool fetch = t + 2 < ntiles;
-    if (fetch) dma_tile(t + 2, (t + 2) % 3);
+    if (fetch && !prefetched) dma_tile(t + 2, (t + 2) % 3);
     if (t < n_mine) tile_masked(t, buf);
     ring_sync(fetch);
   };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  using B2 = std::integral_constant<int, 2>;
 
   // tile 0 landed (Q fragments too: they were issued after tile 1's DMA, so wait for everything)
   asm volatile("" ::: "memory");
@@ -364,27 +449,41 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // (separate loops: the unmasked body must not share a control-flow merge with the masked one,
-  //  or the accumulators get copied at every join)
+  // Unmasked tiles: one exact tile (the first one, or the one a lazy tile bailed out of -- its prefetch is then already
+  // issued), followed by lazy tiles until one bails out.  Separate loops on purpose: bodies that merge control flow get
+  // their accumulators copied at every join.  `buf` = t % 3, carried along (tile t + 2 goes to slot (buf + 2) % 3).
 #ifdef FA_STAMPS
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
   begin_ = last_;
 #endif
-  int t = 0;
-  for (; t + 3 <= nfull; t += 3) {
-    step_full(t, B0{});
-    step_full(t + 1, B1{});
-    step_full(t + 2, B2{});
-  }
-  if (t < nfull) {
-    step_full(t, B0{});
+  int t = 0, buf = 0;
+  bool prefetched = false;
+  auto next_slot = [](int b) __attribute__((always_inline)) { return b == 2 ? 0 : b + 1; };
+  while (t < nfull) {
+    const bool fetch = t + 2 < ntiles;
+    if (fetch && !prefetched) dma_tile(t + 2, next_slot(next_slot(buf)));
+    FA_STAMP(0);  // DMA issue
+    tile_full(buf);
+    FA_STAMP(4);  // P V MFMAs
+    ring_sync(fetch);
+    FA_STAMP(5);  // vmcnt + barrier
     ++t;
-    if (t < nfull) {
-      step_full(t, B1{});
-      ++t;
+    buf = next_slot(buf);
+    prefetched = false;
+    for (; t < nfull; ++t, buf = next_slot(buf)) {
+      const bool fetch2 = t + 2 < ntiles;
+      if (fetch2) dma_tile(t + 2, next_slot(next_slot(buf)));
+      if (!tile_lazy(buf)) {
+        prefetched = true;
+        break;
+      }
+      ring_sync(fetch2);
     }
   }
-  for (; t < ntiles; ++t) step_tail(t);
+  for (; t < ntiles; ++t) {
+    step_tail(t, prefetched);
+    prefetched = false;
+  }
 
 #ifdef FA_STAMPS
   unsigned long long loop_end_;
@@ -396,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     const float lt = half_sum(l[j]);
     const float inv = 1.0f / lt;
     store_tile_rows<D, T>(oacc[j], inv, smem + (wave * 2 + j) * 32 * C::ROWB, ro, (qw0 + 32 * j) * C::ROWB, lane);
-    if (h == 0) buf_store_f32(rl, (qw0 + 32 * j + r) * 4, m[j] * p.scale + __builtin_logf(lt));
+    if (h == 0) buf_store_f32(rl, (qw0 + 32 * j + r) * 4, m[j] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
   }
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {
