@@ -22,6 +22,9 @@
 namespace fa {
 
 // A/B hook (as fa_fwd.hip FA_FWD_PRIO): 1 = raise the wave's priority over the MFMA chains of a lazy tile
+#ifndef FA_FWD2_INTERLEAVE
+#define FA_FWD2_INTERLEAVE 1  // A/B hook: 0 = the wave's two query blocks are adjacent also on causal launches
+#endif
 #ifndef FA_FWD2_PRIO
 #define FA_FWD2_PRIO 1
 #endif
@@ -83,7 +86,13 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
   const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
   const int q0_wg = qt * C::BM;
-  const int qw0 = q0_wg + wave * 64;
+  // The wave's two 32-row query blocks.  Causal: blocks w and w + 4 of the workgroup's eight (rows 32w.. and 128 + 32w..),
+  // so that every wave has one early and one late diagonal -- with two adjacent blocks (rows 64w..) wave 0 is done three
+  // tiles before wave 3 and each of the last four steps of a pass waits for one wave's two-block diagonal tile.
+  // Non-causal: the mapping is irrelevant (every block sees every key); adjacent blocks keep the O stores contiguous.
+  const int qrow0 = q0_wg + (FA_FWD2_INTERLEAVE && CAUSAL ? 32 * wave : 64 * wave);
+  const int qrow1 = qrow0 + (FA_FWD2_INTERLEAVE && CAUSAL ? 128 : 32);
+  auto qrow = [&](int j) __attribute__((always_inline)) { return j == 0 ? qrow0 : qrow1; };
   if (pass) __syncthreads();  // the previous pass staged its O tile in the ring
 
   const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
@@ -99,9 +108,10 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   // ---- tile schedule (wave-uniform) ----
   const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
   const int ntiles = (kv_end + C::BN - 1) / C::BN;                    // tiles the workgroup streams
-  int n_mine = CAUSAL ? min(ntiles, qw0 / C::BN + 1) : ntiles;        // tiles this wave computes
-  if (qw0 >= p.Sq) n_mine = 0;                                        // wave entirely past the last row
-  const int nfull = min(n_mine, CAUSAL ? min(p.Sk / C::BN, qw0 / C::BN) : p.Sk / C::BN);  // unmasked ones
+  int n_mine = CAUSAL ? min(ntiles, qrow1 / C::BN + 1) : ntiles;      // tiles this wave computes (its later block)
+  if (qrow0 >= p.Sq) n_mine = 0;                                      // wave entirely past the last row
+  // tiles BOTH blocks see unmasked: the two-block fast path; from there to n_mine each block runs on its own
+  const int nfull = min(n_mine, CAUSAL ? min(p.Sk / C::BN, qrow0 / C::BN) : p.Sk / C::BN);
 
   // A DMA whose source is out of range may leave its LDS bytes untouched; a ragged last tile must
   // not expose uninitialised LDS (0 * NaN in P V), so clear the ring once.  Later rounds only ever
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
-      qf[j][ks] = as_vec8<T>(buf_load16(rq, (qw0 + 32 * j + r) * C::ROWB + (2 * ks + h) * 16));
+      qf[j][ks] = as_vec8<T>(buf_load16(rq, (qrow(j) + r) * C::ROWB + (2 * ks + h) * 16));
 
   int k_off[C::KS];
 #pragma unroll
@@ -396,14 +406,15 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
     return true;
   };
   // masked tile (causal diagonal and/or ragged key tail) on the exact path.  (Trying the lazy path first, per query
-  // block, measured -0.9 % causal: the extra body and its control-flow joins cost more than the one tile per pass saves.)
+  // block, measured -0.9 % with adjacent blocks and -3 % with the interleaved ones: the extra body and its control-flow
+  // joins cost more than the four single-block tiles per wave and pass save.)
   auto tile_masked = [&](int t, int buf) __attribute__((always_inline)) {
     const FA_LDS char* kt = smem + buf * C::TILE_BYTES;
     const FA_LDS char* vt = smem + C::V_BASE + buf * C::TILE_BYTES;
     const int s0k = t * C::BN;
     auto one = [&](auto jt) __attribute__((always_inline)) {
       constexpr int j = decltype(jt)::value;
-      const int qb0 = qw0 + 32 * j;
+      const int qb0 = qrow(j);
       bool use[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) use[b] = (s0k + 32 * b < p.Sk) && (!CAUSAL || s0k + 32 * b <= qb0);
@@ -494,8 +505,8 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   for (int j = 0; j < 2; ++j) {
     const float lt = half_sum(l[j]);
     const float inv = 1.0f / lt;
-    store_tile_rows<D, T>(oacc[j], inv, smem + (wave * 2 + j) * 32 * C::ROWB, ro, (qw0 + 32 * j) * C::ROWB, lane);
-    if (h == 0) buf_store_f32(rl, (qw0 + 32 * j + r) * 4, m[j] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
+    store_tile_rows<D, T>(oacc[j], inv, smem + (wave * 2 + j) * 32 * C::ROWB, ro, qrow(j) * C::ROWB, lane);
+    if (h == 0) buf_store_f32(rl, (qrow(j) + r) * 4, m[j] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
   }
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {

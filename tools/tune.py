@@ -39,7 +39,7 @@ def rule_family(kernel, D, dtype, causal, bh, S):
     return 2 if (not causal and wgs2 >= 512) else 1
 
 
-def measure(out_path, rounds, reps):
+def measure(out_path, rounds, reps, min_ms):
     sys.path.insert(0, PKG)
     import torch
     import _mi355fa as host
@@ -75,7 +75,12 @@ def measure(out_path, rounds, reps):
                         for ki, kern in enumerate(KERNELS):
                             cands = CANDIDATES[kern][D]
                             times = {c: [] for c in cands}
-                            n = max(3, min(reps, int(2e-3 / max(1e-6, 4 * bh * S * S * D * 1e-15)) + 3))
+                            # launches per timing: at least `min_ms` of back-to-back work (estimated at ~1 PFLOP/s), so that
+                            # every candidate is timed at the clock the chip HOLDS -- in 2 ms bursts the headline forward
+                            # of family 1 beat family 2 by 3.5 %, under sustained load (tools/kbench.py, bench.py) it is the
+                            # other way round (the 64-rows-per-wave kernel moves half the LDS bytes)
+                            est_ms = max(2e-3, 4 * bh * S * S * D * (1 if kern == "fwd" else 2.5) * (0.5 if causal else 1) * 1e-12)
+                            n = max(3, min(reps, int(min_ms / est_ms) + 1))
                             for rnd in range(rounds + 1):
                                 for c in cands:
                                     f = [0, 0, 0]
@@ -166,10 +171,11 @@ if __name__ == "__main__":
     ap.add_argument("--emit")
     ap.add_argument("--emit-rule", action="store_true")
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--reps", type=int, default=2000)
+    ap.add_argument("--min-ms", type=float, default=10.0, help="back-to-back work per timing (sustained clocks)")
     a = ap.parse_args()
     if a.measure:
-        measure(a.measure, a.rounds, a.reps)
+        measure(a.measure, a.rounds, a.reps, a.min_ms)
     if a.emit:
         emit(json.load(open(a.emit))["points"], os.path.relpath(a.emit, ROOT))
     if a.emit_rule:
