@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355fa.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 FP16, BF16 = 0, 1
 
 _vp, _i, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ulonglong
@@ -23,7 +23,7 @@ class Opts(ctypes.Structure):
                 [(n, _sp) for n in ("q_strides", "k_strides", "v_strides", "o_strides", "dout_strides", "dq_strides",
                                     "dk_strides", "dv_strides")] +
                 [("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp), ("total_q", _i), ("total_k", _i),
-                 ("p_drop", _f), ("seed", _u64), ("offset", _u64)])
+                 ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("q_scaled", _vp)])
 
     @classmethod
     def make(cls, **kw):

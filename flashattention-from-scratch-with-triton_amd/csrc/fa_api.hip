@@ -206,8 +206,12 @@ static int dq_impl(const char* fn, const void* q, const void* k, const void* v, 
   fa::BwdParams p{q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, B, H, S_q, S_k, scale, 0, g_dbg, 0};
   if (int rc = bwd_fill(fn, &p, x, B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(o) || misaligned(dout) || misaligned(lse) ||
-      misaligned(dq) || misaligned(delta))
+      misaligned(dq) || misaligned(delta) || misaligned(x.q_scaled))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+  if (x.q_scaled && dtype == MI355FA_BF16) {  // workspace the dK/dV launch will read instead of Q (fa_kernels.h BwdParams::qs)
+    p.qs = x.q_scaled;
+    p.lqs = x.cu_seqlens_q ? packed_layout(H, D) : fa::contiguous_layout(H, S_q, D);
+  }
   hipError_t e = fa::launch_bwd_dq(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, fn);
   return 0;
@@ -222,8 +226,13 @@ static int dkv_impl(const char* fn, const void* q, const void* k, const void* v,
   fa::BwdParams p{q, k, v, nullptr, dout, lse, const_cast<float*>(delta), nullptr, dk, dv, B, H, S_q, S_k, scale, 0, g_dbg, 0};
   if (int rc = bwd_fill(fn, &p, x, B, H, S_q, S_k, D, dtype)) return rc;
   if (misaligned(q) || misaligned(k) || misaligned(v) || misaligned(dout) || misaligned(lse) || misaligned(delta) ||
-      misaligned(dk) || misaligned(dv))
+      misaligned(dk) || misaligned(dv) || misaligned(x.q_scaled))
     return fail(MI355FA_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+  if (x.q_scaled && dtype == MI355FA_BF16) {  // the rows the dQ launch wrote: Q * scale * log2e as the forward rounded it
+    p.q = x.q_scaled;
+    p.lq = x.cu_seqlens_q ? packed_layout(H, D) : fa::contiguous_layout(H, S_q, D);
+    p.q_prescaled = 1;
+  }
   hipError_t e = fa::launch_bwd_dkv(p, D, dtype, causal != 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, fn);
   return 0;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   for (int ks = 0; ks < C::KS; ++ks) {
     const int off = (kw0 + r) * kv_rs + (2 * ks + h) * 16;
     kf[ks] = as_vec8<T>(buf_load16(rk, off));
-    if constexpr (FOLD) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
+    if (FOLD && !p.q_prescaled) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
     vf[ks] = as_vec8<T>(buf_load16(rv, off));
   }
 
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   }
 
   FA_LDS char* stage = smem + wave * 32 * C::ROWB;
-  store_tile_rows<D, T>(dkacc, p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
+  // dK = dS^T Q * scale; with the pre-scaled Q (= Q * scale * log2e) in LDS that is dS^T Q' * ln 2
+    store_tile_rows<D, T>(dkacc, (FOLD && p.q_prescaled) ? kLn2 : p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
   store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
   }  // pass
 }

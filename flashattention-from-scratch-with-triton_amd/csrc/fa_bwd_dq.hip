@@ -271,6 +271,17 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     tile_sync();
   }
 
+  if constexpr (FOLD) {
+    if (p.qs) {  // workspace for the dK/dV launch: the scaled rows exactly as this kernel (and the forward) multiplied
+                 // them; stored here, not in the prologue, where the first tile's vmcnt(0) would wait for them
+      const __amdgpu_buffer_rsrc_t rqs = make_rsrc(
+          (char*)p.qs + b_ * p.lqs.sb + h_ * p.lqs.sh + (long long)si.q0 * p.lqs.rs, (unsigned)(Sq - 1) * p.lqs.rs + C::ROWB);
+      const int ln = lane_id_now();  // re-derived: nothing lane-dependent is kept live across the tile loop for this
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks)
+        buf_store16(rqs, (qw0 + (ln & 31)) * p.lqs.rs + (2 * ks + (ln >> 5)) * 16, __builtin_bit_cast(u32x4, qf[ks]));
+    }
+  }
   store_tile_rows<D, T>(dqacc, p.scale, smem + wave * 32 * C::ROWB, rdq, qw0 * dq_rs, lane, dq_rs);
   }  // pass
 }

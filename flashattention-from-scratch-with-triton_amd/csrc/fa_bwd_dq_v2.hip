@@ -134,6 +134,16 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq2_kernel(BwdParams p) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) qf[j][ks] = scale_frag<T>(qf[j][ks], c2);
   }
+  if constexpr (FOLD) {
+    if (p.qs) {  // workspace for the dK/dV launch (fa_kernels.h BwdParams::qs); this family runs on contiguous tensors only
+      const __amdgpu_buffer_rsrc_t rqs = make_rsrc((char*)p.qs + qoff, (unsigned)p.Sq * C::ROWB);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks)
+          buf_store16(rqs, (qw0 + 32 * j + r) * C::ROWB + (2 * ks + h) * 16, __builtin_bit_cast(u32x4, qf[j][ks]));
+    }
+  }
   f32x16 dqacc[2][C::DB];
 #pragma unroll
   for (int j = 0; j < 2; ++j)

@@ -102,6 +102,13 @@ struct BwdParams {
   int pair;         // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
   TensorLayout lq, lk, lv, ldo;  // K and V share their row stride (checked by the C ABI)
   TensorLayout lo, ldq, ldk, ldv;  // O (input of the dQ kernel) and the gradient outputs: contiguous, strided, or packed rows (varlen)
+  // bf16 scale fold, optional workspace (include/mi355fa.h mi355fa_opts.q_scaled): the dQ kernel writes the Q it actually
+  // multiplies -- bf16(Q * softmax_scale * log2e), the operand the forward's LSE was computed from -- to `qs` (layout lqs);
+  // the dK/dV launch then gets that buffer as `q` (q_prescaled = 1) and leaves K alone, so its recomputed P is consistent
+  // with LSE at any score magnitude.  qs == nullptr / q_prescaled == 0: dK/dV folds the scale into K (its own rounding).
+  void* qs;
+  TensorLayout lqs;
+  int q_prescaled;
   long long lse_sb, lse_sh;        // LSE / delta element strides per batch / head
   VarLen vl;
   DropoutParams drop;

@@ -173,6 +173,11 @@ std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor
   Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
   Strides3 sq(Q), sk(K), sv(V), so(O), sdo(dO), sdq(dQ), sdk(dK), sdv(dV);
   mi355fa_opts x = make_opts(p_drop, seed, offset);
+  Tensor qs;  // bf16: the dQ launch leaves the Q rows it multiplied here for the dK/dV launch (mi355fa_opts.q_scaled)
+  if (dt == MI355FA_BF16) {
+    qs = torch::empty({B, H, Sq, D}, Q.options());
+    x.q_scaled = qs.data_ptr();
+  }
   x.q_strides = sq.ptr;
   x.k_strides = sk.ptr;
   x.v_strides = sv.ptr;
@@ -285,6 +290,11 @@ std::tuple<Tensor, Tensor, Tensor> varlen_backward_launch(const Tensor& Q_, cons
   const float scale = (float)(1.0 / std::sqrt((double)D));
   const int dt = dtype_code(Q);
   mi355fa_opts x = make_opts(p_drop, seed, offset);
+  Tensor qs;  // bf16: Q rows as the dQ launch multiplied them, for the dK/dV launch (mi355fa_opts.q_scaled)
+  if (dt == MI355FA_BF16) {
+    qs = torch::empty({Tq, H, D}, Q.options());
+    x.q_scaled = qs.data_ptr();
+  }
   x.cu_seqlens_q = (const int*)cu_q.data_ptr();
   x.cu_seqlens_k = (const int*)cu_k.data_ptr();
   x.total_q = (int)Tq;

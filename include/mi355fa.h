@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355FA_ABI_VERSION 6
+#define MI355FA_ABI_VERSION 7
 
 /* dtype codes */
 #define MI355FA_FP16 0
@@ -157,6 +157,13 @@ int fa_bwd_dkv_dropout(const void* q, const void* k, const void* v, const void* 
  *   - p_drop / seed / offset: attention dropout as for the *_dropout functions.  With cu_seqlens the Philox counter uses
  *     the position INSIDE each sequence and slice index (sequence * H + head), so a packed batch drops exactly the weights
  *     the same sequences would lose in a padded [B, H, S, D] launch with the same (seed, offset).
+ *   - q_scaled (backward only, optional): a workspace of Q's size, contiguous [B, H, S_q, D] (packed [total_q, H, D] with
+ *     cu_seqlens), given to BOTH fa_bwd_dq_ex and fa_bwd_dkv_ex of one backward pass.  bf16 only (ignored for fp16): the
+ *     bf16 kernels fold softmax_scale * log2(e) into a 16-bit operand -- forward and dQ into Q, dK/dV into K, whose
+ *     rounding is independent of the one behind LSE, so the dK / dV error grows with the score magnitude (about
+ *     4.5e-4 * max|score * scale * log2 e| relative).  With the workspace the dQ launch stores the Q rows it multiplies and
+ *     the dK/dV launch reads those instead of Q and leaves K alone: P is recomputed from exactly the operands LSE came
+ *     from and dK / dV stay at the accuracy of O and dQ for any magnitude.  NULL = no workspace (the behaviour above).
  * opts == NULL is the plain launch (fa_fwd / fa_bwd_dq / fa_bwd_dkv). */
 typedef struct mi355fa_opts {
   unsigned size;
@@ -165,6 +172,7 @@ typedef struct mi355fa_opts {
   int total_q, total_k;
   float p_drop;
   unsigned long long seed, offset;
+  void* q_scaled;
 } mi355fa_opts;
 
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,

@@ -245,6 +245,29 @@ def test_large_magnitude_scores_bf16(impl, causal):
     assert fo.rel_fro(gt["LSE"], r["LSE"]) < 2e-3
 
 
+@pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
+def test_large_magnitude_scores_bf16_with_the_scaled_q_workspace(causal):
+    """The same stress through flash_attention(): its backward hands the dQ and dK/dV launches one workspace
+    (mi355fa_opts.q_scaled), the dK/dV kernel then recomputes P from exactly the rounded operand LSE came from, and dK / dV
+    hold the bound of O and dQ (2.5x PyTorch's own bf16 SDPA) instead of the magnitude-dependent one above."""
+    M = _host()
+    B, H, S, D = 1, 2, 384, 64
+    Q, K, V, dO = rand_inputs(B, H, S, S, D, BF16, seed=21)
+    Q, K = (Q.float() * 2.5).to(BF16), (K.float() * 2.5).to(BF16)
+    gt = fo.attention_fp64(Q, K, V, dO, causal)
+    peer = dict(zip(("O", "dQ", "dK", "dV"), fo.cpu_sdpa(Q, K, V, causal, dO)))
+    q, k, v = (x.cuda().requires_grad_(True) for x in (Q, K, V))
+    o = M.flash_attention(q, k, v, causal)
+    o.backward(dO.cuda())
+    raw = run_gpu_raw(Q, K, V, dO, causal)               # no workspace: the C ABI's plain entry points
+    for name, got in (("O", o.detach()), ("dQ", q.grad), ("dK", k.grad), ("dV", v.grad)):
+        ours, theirs = fo.rel_fro(gt[name], got.cpu()), fo.rel_fro(gt[name], peer[name])
+        assert ours < max(2.5 * theirs, 6e-3), (name, ours, theirs)
+    for name, got in (("dK", k.grad), ("dV", v.grad)):   # and it is the workspace that does it
+        assert fo.rel_fro(gt[name], got.cpu()) < 0.6 * fo.rel_fro(gt[name], raw[name]), name
+    assert torch.equal(o.detach().cpu(), raw["O"]) and torch.equal(q.grad.cpu(), raw["dQ"])
+
+
 # ---------------------------------------------------------------- (3) torch SDPA on the device
 @pytest.mark.parametrize("dtype", [F16, BF16])
 def test_compare_with_sdpa_on_device(dtype):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_functions():
         assert hasattr(raw, name), name
         assert name in fa.SIGNATURES, "python binding misses " + name
-    assert fa.lib.fa_abi_version() == 6
+    assert fa.lib.fa_abi_version() == 7
     assert fa.lib.fa_supported(64, fa.BF16) == 1 and fa.lib.fa_supported(128, fa.FP16) == 1
     assert fa.lib.fa_supported(96, fa.BF16) == 0 and fa.lib.fa_supported(64, 7) == 0
 
@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_torch_binding_loads_and_matches_the_abi():
     import _mi355fa as fa
     import _mi355fa_torch as ext
-    assert ext.abi_version() == fa.ABI_VERSION == 6
+    assert ext.abi_version() == fa.ABI_VERSION == 7
     for name in ("flash_attention", "forward_launch", "backward_launch", "flash_attention_varlen", "varlen_forward_launch",
                  "varlen_backward_launch", "flash_attention_dropout", "dropout_forward_launch", "dropout_backward_launch"):
         assert callable(getattr(ext, name)), name
@@ -107,7 +107,7 @@ def test_general_entry_points_validate_their_options():
     assert L.fa_bwd_dkv_ex(p, p, p, p, p, p, p, p, *args, ctypes.byref(fa.Opts.make(p_drop=1.0)), None) == -2
     assert b"dropout" in L.fa_last_error()
     assert L.fa_fwd_ex(None, p, p, p, p, *args, None, None) == -1                 # opts == NULL is the plain launch
-    assert ctypes.sizeof(fa.Opts) == 120                                          # layout of mi355fa_opts on LP64
+    assert ctypes.sizeof(fa.Opts) == 128                                          # layout of mi355fa_opts on LP64
 
 
 def test_schedule_table_lookup_and_override():
