@@ -69,7 +69,12 @@ def test_random_shape_against_fp64_and_itself(case):
         if dtype == F16:
             assert err < max(1.5 * fo.rel_fro(gt[k], peer[k]), 1e-3), (k, err)
         else:
-            assert err < max(2 * fo.rel_fro(gt[k], peer[k]), 4e-3), (k, err)
+            # bf16 scale fold: Q is rounded once more after the multiply by scale * log2e, i.e. the
+            # kernels compute the attention of a Q half a bf16 ulp away.  Over many keys that averages out; with two or
+            # three keys per row a gradient that is pure cancellation moves by up to ~3x the reference algorithm's own
+            # error (B1 H2 2x2 non-causal, seed 4242: 1.8e-2 against 6.7e-3, reproduced on the CPU by rounding Q only)
+            few = min(Sq, Sk) <= 4
+            assert err < max((3 if few else 2) * fo.rel_fro(gt[k], peer[k]), 4e-3), (k, err)
 
 
 @pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
