@@ -143,15 +143,20 @@ def kernel_times(M, Q, K, V, dO, causal, reps):
     scale = 1 / (D ** 0.5)
     st = torch.cuda.current_stream().cuda_stream
     c = int(causal)
+    # the backward launches as the autograd path issues them: bf16 passes the scaled-Q workspace (mi355fa_opts.q_scaled)
+    import ctypes
+    qs = torch.empty_like(Q) if Q.dtype == torch.bfloat16 else None
+    opts = fa.Opts.make(q_scaled=qs.data_ptr()) if qs is not None else None
+    op = ctypes.byref(opts) if opts is not None else None
     launches = {
         "fa_fwd": lambda: fa.lib.fa_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), LSE.data_ptr(),
                                         B, H, Sq, Sk, D, dt, c, scale, st),
-        "fa_bwd_dq": lambda: fa.lib.fa_bwd_dq(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(),
-                                              LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
-                                              B, H, Sq, Sk, D, dt, c, scale, st),
-        "fa_bwd_dkv": lambda: fa.lib.fa_bwd_dkv(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(),
-                                                LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                                                B, H, Sq, Sk, D, dt, c, scale, st),
+        "fa_bwd_dq": lambda: fa.lib.fa_bwd_dq_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(),
+                                                 LSE.data_ptr(), dQ.data_ptr(), delta.data_ptr(),
+                                                 B, H, Sq, Sk, D, dt, c, scale, op, st),
+        "fa_bwd_dkv": lambda: fa.lib.fa_bwd_dkv_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(),
+                                                   LSE.data_ptr(), delta.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                                                   B, H, Sq, Sk, D, dt, c, scale, op, st),
     }
     out = {}
     for name, fn in launches.items():
