@@ -95,15 +95,20 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   auto qrow = [&](int j) __attribute__((always_inline)) { return j == 0 ? qrow0 : qrow1; };
   if (pass) __syncthreads();  // the previous pass staged its O tile in the ring
 
-  const char* qb = (const char*)p.q + (size_t)bh * p.Sq * C::ROWB;
-  const char* kb = (const char*)p.k + (size_t)bh * p.Sk * C::ROWB;
-  const char* vb = (const char*)p.v + (size_t)bh * p.Sk * C::ROWB;
-  char* ob = (char*)p.o + (size_t)bh * p.Sq * C::ROWB;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)p.Sk * C::ROWB);
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)p.Sq * C::ROWB);
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + (size_t)bh * p.Sq, (unsigned)p.Sq * 4);
+  // Q, K, V, O may be strided views with a contiguous head dim (fa_fwd.hip): per-tensor batch / head byte strides, one
+  // row stride for Q, one shared by K and V, one for O.  (No variable-length launches here: the launcher sends those to
+  // family 1.)
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int q_rs = p.lq.rs, kv_rs = p.lk.rs, o_rs = p.lo.rs;
+  const char* qb = (const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh;
+  const char* kb = (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh;
+  const char* vb = (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh;
+  char* ob = (char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)(p.Sq - 1) * q_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)(p.Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)(p.Sq - 1) * o_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)p.Sq * 4);
 
   // ---- tile schedule (wave-uniform) ----
   const int kv_end = CAUSAL ? min(p.Sk, q0_wg + C::BM) : p.Sk;
@@ -129,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = 16 * wave + 8 * i + (lane >> 3);
     // dma_pieces (fa_common.h): piece i carries the immediate offset 1024*i, which also moves the global address
-    dma_src[i] = row * C::ROWB + swz_chunk<D>(row, lane & 7) * 16 - 1024 * i;
+    dma_src[i] = row * kv_rs + swz_chunk<D>(row, lane & 7) * 16 - 1024 * i;
   }
   auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
-    const int soff = t * C::TILE_BYTES;
+    const int soff = t * C::BN * kv_rs;
     const int dst0 = buf * C::TILE_BYTES + 16 * wave * C::ROWB;  // this wave's 16 rows = DMA_PER_MAT consecutive KiB
     dma_pieces<C::DMA_PER_MAT>(rk, lds_addr_of(smem + dst0), dma_src, soff);
     dma_pieces<C::DMA_PER_MAT>(rv, lds_addr_of(smem + C::V_BASE + dst0), dma_src, soff);
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
-      qf[j][ks] = as_vec8<T>(buf_load16(rq, (qrow(j) + r) * C::ROWB + (2 * ks + h) * 16));
+      qf[j][ks] = as_vec8<T>(buf_load16(rq, (qrow(j) + r) * q_rs + (2 * ks + h) * 16));
 
   int k_off[C::KS];
 #pragma unroll
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void fa_fwd2_kernel(FwdParams p) {
   for (int j = 0; j < 2; ++j) {
     const float lt = half_sum(l[j]);
     const float inv = 1.0f / lt;
-    store_tile_rows<D, T>(oacc[j], inv, smem + (wave * 2 + j) * 32 * C::ROWB, ro, qrow(j) * C::ROWB, lane);
+    store_tile_rows<D, T>(oacc[j], inv, smem + (wave * 2 + j) * 32 * C::ROWB, ro, qrow(j) * o_rs, lane, o_rs);
     if (h == 0) buf_store_f32(rl, (qrow(j) + r) * 4, m[j] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
   }
 #ifdef FA_STAMPS

@@ -137,7 +137,7 @@ inline hipError_t opt_in_lds(const void* kern, int bytes, std::atomic<unsigned l
 // ---- schedule selection: the counterpart of the reference's autotune key (S_q, S_k, D, is_causal), K:18-32 --------
 // A table generated offline (tools/tune.py -> fa_table.h) instead of a run-time search.  Schedule families:
 //   forward   1 = fa_fwd.hip      128-row workgroups, 32 rows per wave, up to 3 waves per SIMD  (D = 64, 128)
-//             2 = fa_fwd_v2.hip   256-row workgroups, 64 rows per wave sharing every K/V fragment (D = 64, contiguous)
+//             2 = fa_fwd_v2.hip   256-row workgroups, 64 rows per wave sharing every K/V fragment (D = 64, fixed length)
 //             3 = fa_fwd_v3.hip   128-row workgroups, per-wave three-stage software pipeline (D = 64)
 //   dQ        1 = fa_bwd_dq.hip   as forward 1;  2 = fa_bwd_dq_v2.hip as forward 2;
 //             3 = fa_bwd_dq_v3.hip  128-row workgroups, per-wave three-stage software pipeline (D = 64)
@@ -161,9 +161,10 @@ inline int table_family(int kernel, int D, int dtype, bool causal, long bh, long
                        [nearest_log2_bucket(S, table::kS, table::kNumS)];
 }
 // (launches with dropout always take family 1: the dropout variants exist for that family only)
-inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
+// `fixed_length`: not a variable-length launch (the family-2 forward reads strided views, but not packed batches)
+inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool fixed_length) {
   int f = forced ? forced : table_family(kKernelFwd, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
-  if (f == 2 && (D != 64 || !contiguous)) f = 1;
+  if (f == 2 && (D != 64 || !fixed_length)) f = 1;
   if (f == 3 && D != 64) f = 1;
   return (f == 2 || f == 3) ? f : 1;
 }

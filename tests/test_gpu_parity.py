@@ -396,8 +396,8 @@ def test_strided_views_are_read_in_place_and_bit_identical(D, causal, dtype, imp
     they give on contiguous copies of the same data -- same arithmetic, different addressing."""
     M = _host()
     import _mi355fa as fa
-    if impl == 2:   # strided views always take family 1 for forward / dQ: pin it for the contiguous twin as well
-        fa.lib.fa_debug_force_impl(1, 1, 2)
+    if impl == 2:   # strided views take family 1 for dQ (the family-2 forward reads views): pin it for the contiguous twin
+        fa.lib.fa_debug_force_impl(2, 1, 2)
     B, H, Sq = 2, 3, 333
     torch.manual_seed(3)
     qkv = torch.randn(B, Sq, 3, H, D, device="cuda", dtype=dtype)
