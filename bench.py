@@ -76,6 +76,10 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--non-causal", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-s", type=float, default=0.5,
+                    help="seconds of the SAME step run untimed before the --warmup/--steps window (clock settle: the first "
+                         "~40 steps after an idle period run in a DVFS transient, first above and then below the steady "
+                         "clock); reported as preroll_s; 0 disables")
     ap.add_argument("--no-config5", action="store_true", help="skip the extra config-5 measurement of a default run")
     ap.add_argument("--layout", default="bhsd", choices=["bhsd", "bshd"],
                     help="bhsd: contiguous [B,H,S,D] inputs (the BASELINE config); bshd: Q/K/V are transposed views of "
@@ -210,7 +214,7 @@ def traffic_for(kernel, shape_key):
     return t.get(kernel, {}).get("bytes")
 
 
-def measure(M, dev, rank, world, lo, hi, H, S, D, dtype, causal, steps, warmup, layout="bhsd", with_fwd=True):
+def measure(M, dev, rank, world, lo, hi, H, S, D, dtype, causal, steps, warmup, layout="bhsd", with_fwd=True, preroll_s=0.0):
     """Timed fwd+bwd steps (and forward-only steps) on this rank's batch shard [lo, hi)."""
     Q, K, V, dO = sc.make_shard(lo, hi, H, S, S, D, dtype, dev)
     if layout == "bshd":   # same values, stored [B,S,H,D]; the step sees [B,H,S,D] views
@@ -231,10 +235,10 @@ def measure(M, dev, rank, world, lo, hi, H, S, D, dtype, causal, steps, warmup, 
         with torch.no_grad():
             M.flash_attention(Q, K, V, causal)
 
-    ms_total = sc.timed_steps(step, steps, warmup, dev)
+    ms_total = sc.timed_steps(step, steps, warmup, dev, preroll_s)
     res = {"ms_step": ms_total / steps, "tensors": (Q, K, V, dO)}
     if with_fwd:
-        res["ms_fwd"] = sc.timed_steps(step_fwd, steps, min(warmup, 3), dev) / steps
+        res["ms_fwd"] = sc.timed_steps(step_fwd, steps, min(warmup, 3), dev, preroll_s) / steps
     if layout == "bshd":   # what the reference's binding does with such views (M:138-140): copy, then run
         def step_fwd_copy():
             with torch.no_grad():
@@ -282,7 +286,8 @@ def run_rank(args):
         if hi - lo == 0:
             fail("rank %d of %d has an empty shard of global batch %d" % (rank, world, B))
 
-    m = measure(M, dev, rank, world, lo, hi, H, S, D, dtype, causal, args.steps, args.warmup, args.layout)
+    m = measure(M, dev, rank, world, lo, hi, H, S, D, dtype, causal, args.steps, args.warmup, args.layout,
+                preroll_s=args.preroll_s)
     ms_step, ms_fwd = m["ms_step"], m["ms_fwd"]
     F_job = flops_fwd(GB, H, S, S, D, causal)            # whole job
     tf_step = 3.5 * F_job / (ms_step * 1e-3) / 1e12
@@ -313,7 +318,8 @@ def run_rank(args):
         lo5, hi5 = sc.shard_range(b5, rank, world)
         torch.cuda.empty_cache()
         k5 = max(3, min(args.steps, 10))
-        m5 = measure(M, dev, rank, world, lo5, hi5, h5, s5, d5, torch.bfloat16, True, k5, 2, with_fwd=False)
+        m5 = measure(M, dev, rank, world, lo5, hi5, h5, s5, d5, torch.bfloat16, True, k5, 2, with_fwd=False,
+                     preroll_s=args.preroll_s)
         f5 = 3.5 * flops_fwd(b5, h5, s5, s5, d5, True)
         c5 = {"workload": "GLOBAL B=%d,H=%d,N=%d,D=%d causal bf16 fwd+bwd, batch-sharded (BASELINE configs[4])" % (b5, h5, s5, d5),
               "scaling": "strong", "n_gpus": world, "batch_per_gpu": hi5 - lo5, "steps": k5,
@@ -334,7 +340,7 @@ def run_rank(args):
         line = {
             "metric": metric,
             "value": round(tf_step, 2), "unit": "TFLOPS (fwd+bwd, counted FLOPs)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_s": args.preroll_s,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "FlashAttention fwd+bwd, %s,H=%d,N=%d,D=%d %s %s (BASELINE configs[%s]%s)%s" % (
@@ -386,8 +392,9 @@ def main():
     if args.gpus < 1:
         fail("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        if not args.harness_selftest and torch.cuda.device_count() < args.gpus:   # device_count() does not initialise the GPU
-            fail("--gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+        # no device query here: the parent must not open the GPU before it starts its children (torch.cuda.device_count()
+        # falls back to hipGetDeviceCount when amdsmi discovery fails); every rank checks the device count itself and
+        # exits 2 with "only N GPU(s) visible", which spawn_ranks returns
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     run_rank(args)
 

@@ -76,9 +76,15 @@ def barrier(device):
     _sync(device)
 
 
-def timed_steps(step, steps, warmup, device):
-    """warmup untimed steps, then EXACTLY `steps` steps between barrier+synchronize pairs.
-    Returns the elapsed milliseconds, MAX over ranks."""
+def timed_steps(step, steps, warmup, device, preroll_s=0.0):
+    """`preroll_s` seconds of untimed steps (clock settle), then `warmup` untimed steps, then EXACTLY `steps` steps between
+    barrier+synchronize pairs.  Returns the elapsed milliseconds, MAX over ranks."""
+    if preroll_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < preroll_s:
+            for _ in range(8):
+                step()
+            _sync(device)
     for _ in range(warmup):
         step()
     barrier(device)

@@ -69,8 +69,8 @@ fa::TensorLayout packed_layout(int H, int D) { return fa::TensorLayout{0, (long 
 int check_varlen(const char* fn, const int* cu_q, const int* cu_k, int batch, int H, int total_q, int total_k, int max_q,
                  int max_k, int D, int dtype) {
   if (!cu_q || !cu_k) return fail(MI355FA_ERR_NULL, "%s: NULL cu_seqlens", fn);
-  if (total_q < 1 || total_k < 1 || max_q > total_q || max_k > total_k)
-    return fail(MI355FA_ERR_SHAPE, "%s: need 1 <= max_seqlen <= total tokens", fn);
+  // max_seqlen is an UPPER bound of the sequence lengths (it sizes the grid; a static bound above the token count is fine)
+  if (total_q < 1 || total_k < 1) return fail(MI355FA_ERR_SHAPE, "%s: total tokens must be >= 1", fn);
   if (max_q < 1 || max_k < 1 || batch < 1) return fail(MI355FA_ERR_SHAPE, "%s: batch and max_seqlen must be >= 1", fn);
   // 32-bit buffer offsets are used INSIDE one sequence (rows are H*D*2 bytes apart); the packed tensors may be larger
   if ((long long)max_q * H * D * 2 > (1ll << 31) - 1 || (long long)max_k * H * D * 2 > (1ll << 31) - 1)
@@ -83,9 +83,14 @@ int make_dropout(const char* fn, float p_drop, unsigned long long seed, unsigned
   if (!(p_drop >= 0.f) || p_drop >= 1.f) return fail(MI355FA_ERR_SHAPE, "%s: dropout probability must be in [0, 1)", fn);
   unsigned thresh = (unsigned)(p_drop * 256.f + 0.5f);
   if (thresh > 255u) thresh = 255u;
+  if (p_drop > 0.f && thresh == 0u)   // never a silent "no dropout"
+    return fail(MI355FA_ERR_SHAPE, "%s: dropout probability below 1/512 quantises to 0 (p is kept in 1/256 steps): pass 0 or >= 1/512", fn);
+  // the Philox counter has one free 32-bit word for the offset; folding offset[63:32] into the key would make
+  // (seed, offset) pairs that differ only there collide
+  if (offset >> 32) return fail(MI355FA_ERR_SHAPE, "%s: the dropout offset must be below 2^32", fn);
   out->thresh = thresh;
   out->seed_lo = (unsigned)seed;
-  out->seed_hi = (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32);
+  out->seed_hi = (unsigned)(seed >> 32);
   out->offset = (unsigned)offset;
   out->rp = 256.f / (256.f - (float)thresh);
   return 0;

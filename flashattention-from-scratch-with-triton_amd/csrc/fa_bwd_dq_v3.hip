@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq3_kernel(BwdParams p) {
   const __amdgpu_buffer_rsrc_t rdq = make_rsrc(
       (char*)p.dq + b_ * p.ldq.sb + h_ * p.ldq.sh + (long long)si.q0 * dq_rs, (unsigned)(Sq - 1) * dq_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t rk = make_rsrc(
-      (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+      (const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh + (long long)si.k0 * kv_rs, view_bytes(Sk, kv_rs, C::ROWB));
   const __amdgpu_buffer_rsrc_t rv = make_rsrc(
-      (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+      (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs, view_bytes(Sk, kv_rs, C::ROWB));
   const long long rowc_off = b_ * p.lse_sb + h_ * p.lse_sh + si.q0;
   const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + rowc_off, (unsigned)Sq * 4);
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + rowc_off, (unsigned)Sq * 4);
+
 
   // ---- resident B operands: Q^T and dO^T of this wave's 32 rows; delta (K:210-211, from the rounded O) ----
   vec8 qf[C::KS], dof[C::KS];

@@ -44,6 +44,10 @@ struct BF16 {
   static FA_DEVINL f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // VGPR-accumulator forms (mfma_v_* below): start a chain from c / from 0, continue it
+  template <typename A4> static FA_DEVINL void mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c);
+  template <typename A4> static FA_DEVINL void mfma_v_first0(f32x16& d, u32x4 a, A4 b);
+  template <typename A4> static FA_DEVINL void mfma_v_acc(f32x16& d, u32x4 a, A4 b);
 };
 struct FP16 {
   typedef f16x8 vec8;
@@ -52,7 +56,61 @@ struct FP16 {
   static FA_DEVINL f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  template <typename A4> static FA_DEVINL void mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c);
+  template <typename A4> static FA_DEVINL void mfma_v_first0(f32x16& d, u32x4 a, A4 b);
+  template <typename A4> static FA_DEVINL void mfma_v_acc(f32x16& d, u32x4 a, A4 b);
 };
+
+// MFMA with the accumulator pinned to ARCHITECTURAL VGPRs and the B operand to accumulator registers (inline asm).
+// hipcc picks ONE register form for every MFMA builtin of a kernel: once a kernel needs AGPRs (one wave per SIMD, > 256
+// registers) all its MFMA results land in AGPRs, and a result that VALU code consumes (scores -> exp) is then copied out
+// element by element with v_accvgpr_read (measured: 2.6 extra vector instructions per MFMA in fa_bwd_dkv_v3.hip).  These
+// forms keep such chains in VGPRs while the builtin MFMAs of the same kernel accumulate in AGPRs.
+// What hipcc does not do for them (no hazard padding inside / after an asm statement): the caller guarantees that
+//   * nothing reads or overwrites D within 12 wait states of the statement except the next MFMA of the same chain
+//     (the accumulate chain itself needs none) -- the pipelines that use this consume D one block iteration later;
+//   * A / C come from LDS reads or older VALU results (hipcc still inserts the s_waitcnt for loads it issued itself) and
+//     B was written by to_agpr() long before (an explicit s_nop follows those writes).
+typedef __attribute__((ext_vector_type(4))) unsigned agpr4_t;   // a 128-bit fragment living in a[N:N+3]
+#ifndef FA_MFMA_B_AGPR
+#define FA_MFMA_B_AGPR 0   // 1: the B operand of the mfma_v_* forms must live in AGPRs, 0: in VGPRs
+#endif
+#if FA_MFMA_B_AGPR
+#define FA_MFMA_B(x) "a"(x)
+#else
+#define FA_MFMA_B(x) "v"(x)
+#endif
+#define FA_MFMA_ASM_(NAME, OP)                                                                                      \
+  FA_DEVINL void NAME##_first(f32x16& d, u32x4 a, agpr4_t b, const f32x16& c) {                                    \
+    asm volatile(OP " %0, %1, %2, %3" : "=&v"(d) : "v"(a), FA_MFMA_B(b), "v"(c));                                        \
+  }                                                                                                                \
+  FA_DEVINL void NAME##_first0(f32x16& d, u32x4 a, agpr4_t b) {                                                    \
+    asm volatile(OP " %0, %1, %2, 0" : "=&v"(d) : "v"(a), FA_MFMA_B(b));                                                 \
+  }                                                                                                                \
+  FA_DEVINL void NAME##_acc(f32x16& d, u32x4 a, agpr4_t b) {                                                       \
+    asm volatile(OP " %0, %1, %2, %0" : "+v"(d) : "v"(a), FA_MFMA_B(b));                                                 \
+  }
+FA_MFMA_ASM_(mfma_v_bf16, "v_mfma_f32_32x32x16_bf16")
+FA_MFMA_ASM_(mfma_v_f16, "v_mfma_f32_32x32x16_f16")
+#undef FA_MFMA_ASM_
+template <typename A4> FA_DEVINL void BF16::mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c) { mfma_v_bf16_first(d, a, b, c); }
+template <typename A4> FA_DEVINL void BF16::mfma_v_first0(f32x16& d, u32x4 a, A4 b) { mfma_v_bf16_first0(d, a, b); }
+template <typename A4> FA_DEVINL void BF16::mfma_v_acc(f32x16& d, u32x4 a, A4 b) { mfma_v_bf16_acc(d, a, b); }
+template <typename A4> FA_DEVINL void FP16::mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c) { mfma_v_f16_first(d, a, b, c); }
+template <typename A4> FA_DEVINL void FP16::mfma_v_first0(f32x16& d, u32x4 a, A4 b) { mfma_v_f16_first0(d, a, b); }
+template <typename A4> FA_DEVINL void FP16::mfma_v_acc(f32x16& d, u32x4 a, A4 b) { mfma_v_f16_acc(d, a, b); }
+// a 128-bit value moved into accumulator registers (explicitly: a value DEFINED in AGPRs needs no copy at its uses)
+FA_DEVINL agpr4_t to_agpr(u32x4 v) {
+#if !FA_MFMA_B_AGPR
+  return v;
+#endif
+  agpr4_t o;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o[0]) : "v"(v[0]));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o[1]) : "v"(v[1]));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o[2]) : "v"(v[2]));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o[3]) : "v"(v[3]));
+  return o;
+}
 
 template <typename T>
 FA_DEVINL typename T::vec8 as_vec8(u32x4 v) {
@@ -185,6 +243,22 @@ FA_DEVINL void buf_store16(__amdgpu_buffer_rsrc_t r, int off, u32x4 v) {
 }
 FA_DEVINL void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
+// A sequence with queries but no keys (only a variable-length launch can present one; the fixed-length ABI rejects
+// S_k = 0): there is nothing to attend to.  The forward defines O = 0 and LSE = -inf for its rows, the backward dQ = 0
+// and delta = 0 -- the workgroup zero-fills its `nrows` output rows from `row0` on (rows past the descriptor's range are
+// dropped) and issues no K / V access at all (a descriptor sized (S_k - 1) * stride + row would wrap to ~4 GiB).
+template <int D>
+FA_DEVINL void zero_fill_rows(__amdgpu_buffer_rsrc_t dst, int row0, int nrows, int rs, int tid, int nthreads) {
+  constexpr int CPR = D / 8;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < nrows * CPR; i += nthreads) buf_store16(dst, (row0 + i / CPR) * rs + (i % CPR) * 16, z);
+}
+// byte size of a K / V view of `rows` rows for its buffer descriptor (0 rows -> 0 bytes: every access is out of range)
+// (min / max instead of a select: hipcc lowers the select to v_cndmask, which would put the descriptor word in a VGPR)
+FA_DEVINL unsigned view_bytes(int rows, int rs, int rowb) {
+  return (unsigned)(max(rows, 1) - 1) * rs + (unsigned)(min(rows, 1) * rowb);
 }
 
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds): 64 lanes x 16 B from per-lane global offsets `voff`

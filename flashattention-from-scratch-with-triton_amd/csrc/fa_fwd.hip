@@ -101,10 +101,11 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   const char* vb = (const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh + (long long)si.k0 * kv_rs;
   char* ob = (char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh + (long long)si.q0 * o_rs;
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)(Sq - 1) * q_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)(Sk - 1) * kv_rs + C::ROWB);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, view_bytes(Sk, kv_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, view_bytes(Sk, kv_rs, C::ROWB));
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (unsigned)(Sq - 1) * o_rs + C::ROWB);
   const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + b_ * p.lse_sb + h_ * p.lse_sh + si.q0, (unsigned)Sq * 4);
+
 
   // ---- Q^T fragments (B operand), resident for the whole kernel ----
   vec8 qf[C::KS];
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
 
   // ---- epilogue ----
   const float lt = half_sum(l);
-  const float inv = 1.0f / lt;
+  // lt = 0 only for a variable-length sequence with queries but no keys (S_k = 0: no tile was visited): O = 0, LSE = -inf
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
   store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * o_rs, lane, o_rs);
   if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));

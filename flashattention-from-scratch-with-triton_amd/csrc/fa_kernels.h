@@ -8,8 +8,8 @@
 
 namespace fa {
 
-// Byte strides of one [B, H, S, D] INPUT operand whose D dimension is contiguous: batch, head, row.
-// Outputs (O, LSE, dQ, delta, dK, dV) are always contiguous.
+// Byte strides of one [B, H, S, D] operand whose D dimension is contiguous: batch, head, row.  Inputs and the 16-bit
+// outputs (O, dQ, dK, dV) each carry one; LSE / delta rows of one (batch, head) are always contiguous.
 struct TensorLayout {
   long long sb, sh;
   int rs;
@@ -143,6 +143,8 @@ inline hipError_t opt_in_lds(const void* kern, int bytes, std::atomic<unsigned l
 //             3 = fa_bwd_dq_v3.hip  128-row workgroups, per-wave three-stage software pipeline (D = 64)
 //   dK/dV     1 = fa_bwd_dkv.hip  128-key workgroups, 64-row Q/dO tiles;
 //             2 = fa_bwd_dkv_v2.hip  128-row Q/dO tiles, hand-ordered pipeline (D = 64, 128)
+//             3 = fa_bwd_dkv_v3.hip  256-key workgroups, ONE wave per SIMD with 64 keys, every Q / dO fragment read from
+//                                    LDS once for both key groups, continuous hand-ordered pipeline (D = 64)
 // The table is keyed on (kernel, D, dtype, causal, B*H bucket, S bucket); a family the launch cannot use (strided
 // views for the 64-rows-per-wave kernels, a head dim it does not exist for) falls back to family 1.
 // fa_debug_force_impl() (not in the public header) overrides the table for tests, A/B runs and the tuner; 0 = table.
@@ -177,6 +179,7 @@ inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int 
 inline int pick_dkv_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal) {
   if (D != 64 && D != 128) return 1;
   const int f = forced ? forced : table_family(kKernelDkv, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  if (f == 3) return D == 64 ? 3 : 2;
   return f == 2 ? 2 : 1;
 }
 

@@ -111,8 +111,9 @@ int fa_bwd_dkv_strided(const void* q, const long long* q_strides, const void* k,
  * Layout ("thd", packed): q, o, dout, dq : [total_q, H, D];  k, v, dk, dv : [total_k, H, D];  lse, delta : [H, total_q]
  * (fp32).  Sequence b owns the rows [cu_seqlens_q[b], cu_seqlens_q[b+1]) of the q-side tensors and
  * [cu_seqlens_k[b], cu_seqlens_k[b+1]) of the k-side ones; cu_seqlens_* are DEVICE int32 arrays of batch + 1 entries
- * starting at 0 (prefix sums of the lengths; a length of 0 is allowed).  max_seqlen_* (host values, >= the longest
- * sequence) size the launch grid.  Attention is computed inside each sequence only; causal != 0 applies each sequence's
+ * starting at 0 (prefix sums of the lengths; a length of 0 is allowed on either side: a sequence with queries but no keys
+ * gets O = 0, LSE = -inf, dQ = 0).  max_seqlen_* (host values, >= the longest sequence; any upper bound will do) size the
+ * launch grid.  Rows of the packed outputs that no sequence covers (cu_seqlens[batch] < total) are left untouched.  Attention is computed inside each sequence only; causal != 0 applies each sequence's
  * own top-left aligned mask.  Everything else (ownership, stream, return codes, dQ before dK/dV) is as above. */
 int fa_fwd_varlen(const void* q, const void* k, const void* v, void* o, float* lse, const int* cu_seqlens_q,
                   const int* cu_seqlens_k, int batch, int H, int total_q, int total_k, int max_seqlen_q, int max_seqlen_k,
@@ -132,10 +133,11 @@ int fa_bwd_dkv_varlen(const void* q, const void* k, const void* v, const void* d
  * Same tensors and contract as fa_fwd / fa_bwd_dq / fa_bwd_dkv (contiguous [B, H, S, D]).  Each attention weight
  * P[b, h, q, k] is kept with probability 1 - p and scaled by 1 / (1 - p), else set to 0; LSE is that of the undropped
  * softmax.  The keep decision is a pure function of (b*H + h, q, k, seed, offset): Philox4x32-10 with key =
- * {seed[31:0], seed[63:32] ^ offset[63:32]} and counter = {q >> 2, k >> 2, b*H + h, offset[31:0]} yields the 16 bytes of the
+ * {seed[31:0], seed[63:32]} and counter = {q >> 2, k >> 2, b*H + h, offset} (offset < 2^32, checked) yields the 16 bytes of the
  * 4 x 4 patch around (q, k) -- byte (k & 3) of output word (q & 3) -- and the weight is kept iff its byte >= round(256 p)
  * (p is quantised to multiples of 1/256; fa_dropout_keep_scale(p) returns the exact 1 / (1 - p) in use).  The three
- * kernels must be given the same (p_drop, seed, offset).  p_drop = 0 runs the plain kernels. */
+ * kernels must be given the same (p_drop, seed, offset).  p_drop = 0 runs the plain kernels; 0 < p_drop < 1/512 would
+ * quantise to 0 and is rejected (MI355FA_ERR_SHAPE) instead of silently running without dropout. */
 float fa_dropout_keep_scale(float p_drop);
 int fa_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int S_q, int S_k, int D,
                    int dtype, int causal, float scale, float p_drop, unsigned long long seed, unsigned long long offset,

@@ -324,11 +324,12 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def dropout_keep_mask(B, H, Sq, Sk, p_drop, seed, offset=0):
     """The keep mask the kernels regenerate (include/mi355fa.h, fa_*_dropout): bool [B, H, Sq, Sk] and the scale
     1 / (1 - p) of the quantised p.  Weight (b, h, q, k): byte (k & 3) of word (q & 3) of
-    Philox(counter = {q >> 2, k >> 2, b*H + h, offset[31:0]}, key = {seed[31:0], seed[63:32] ^ offset[63:32]}) >= round(256 p)."""
+    Philox(counter = {q >> 2, k >> 2, b*H + h, offset}, key = {seed[31:0], seed[63:32]}) >= round(256 p); offset < 2^32."""
     import numpy as np
     thresh = min(255, int(p_drop * 256.0 + 0.5))
     k0 = seed & 0xFFFFFFFF
-    k1 = ((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFF
+    assert 0 <= offset < (1 << 32), "the Philox counter has one 32-bit word for the offset (include/mi355fa.h)"
+    k1 = (seed >> 32) & 0xFFFFFFFF
     qg = np.arange((Sq + 3) // 4, dtype=np.uint32)[None, :, None]
     kg = np.arange((Sk + 3) // 4, dtype=np.uint32)[None, None, :]
     bh = np.arange(B * H, dtype=np.uint32)[:, None, None]

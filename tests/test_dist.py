@@ -124,6 +124,31 @@ def test_bench_rank_count_mismatch_is_an_error_not_a_single_process_run():
         assert rc != 0 and not lines and "GPU" in err
 
 
+def test_bench_parent_never_queries_the_gpu_before_it_spawns(monkeypatch):
+    """the spawning parent may not touch anything that can open /dev/kfd (torch.cuda.device_count()
+    falls back to hipGetDeviceCount when amdsmi discovery fails) -- the ranks check the device count themselves."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_parent", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def boom(*a, **k):
+        raise AssertionError("the bench.py parent queried the GPU before spawning its ranks")
+
+    for name in ("device_count", "is_available", "init", "_lazy_init", "set_device", "current_device"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    if hasattr(torch._C, "_cuda_getDeviceCount"):
+        monkeypatch.setattr(torch._C, "_cuda_getDeviceCount", boom)
+    seen = {}
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv: seen.update(n=n, argv=argv) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen["n"] == 2 and not torch.cuda.is_initialized()
+
+
 def test_bench_metric_string_follows_the_arguments():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))

@@ -26,8 +26,8 @@ def _host():
 
 @pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "family1", "family2", "family3"])
 def impl(request):
-    """Run a test under the automatic schedule rule and with each D=64 schedule family forced (family 3 exists for
-    the dQ kernel only: forward and dK/dV then run family 1)."""
+    """Run a test under the automatic schedule rule and with each schedule family forced (a family a launch cannot use
+    -- head dim 128 for the D = 64-only families, packed batches for the 64-rows-per-wave forward -- falls back)."""
     import ctypes
     import _mi355fa as fa
     fn = fa.lib.fa_debug_force_impl

@@ -57,6 +57,10 @@ CASES = [
     ([700, 3, 129], [77, 500, 129], 2, 64, False),        # cross attention per sequence
     ([300, 40, 129], [200, 90, 129], 2, 64, True),        # causal with S_q != S_k in both directions
     ([64, 0, 200], [64, 0, 200], 2, 64, True),            # an empty sequence in the middle
+    ([64, 5, 130], [64, 0, 130], 2, 64, True),            # queries with NO keys: O = 0, dQ = 0, nothing read
+    ([64, 5], [64, 0], 2, 64, False),                     # ... as the last sequence: its K/V rows would lie past the end
+    ([0, 70, 300], [33, 70, 0], 2, 64, True),             # keys with no queries: dK = dV = 0 for them
+    ([200, 9], [200, 0], 2, 128, False),
     ([1000], None, 4, 64, True),                          # batch of one
     ([130, 257, 31], None, 2, 128, True),
     ([130, 257, 31], [100, 257, 300], 2, 128, False),
@@ -80,6 +84,11 @@ def test_varlen_against_fp64_oracle(case, dtype, impl):
         assert torch.isfinite(r[k].float()).all(), k
         err = fo.rel_fro(gt[k], r[k])
         assert err < (1e-3 if dtype == F16 else 6e-3), (k, err)
+    for b in range(len(lq)):   # a side without a partner: exact zeros (include/mi355fa.h "a length of 0 is allowed")
+        if lq[b] > 0 and lk[b] == 0:
+            assert (r["O"][cu_q[b]:cu_q[b + 1]] == 0).all() and (r["dQ"][cu_q[b]:cu_q[b + 1]] == 0).all()
+        if lk[b] > 0 and lq[b] == 0:
+            assert (r["dK"][cu_k[b]:cu_k[b + 1]] == 0).all() and (r["dV"][cu_k[b]:cu_k[b + 1]] == 0).all()
     if causal:   # keys beyond a sequence's query count are invisible: their gradient rows are written, as zeros
         for b in range(len(lq)):
             if lk[b] > lq[b] > 0:

@@ -145,6 +145,9 @@ def test_dropout_arguments_and_keep_scale():
     assert L.fa_fwd_dropout(p, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, 1.0, 1, 0, None) == -2 and b"[0, 1)" in L.fa_last_error()
     assert L.fa_fwd_dropout(p, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, -0.1, 1, 0, None) == -2
     assert L.fa_fwd_dropout(None, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, 0.1, 1, 0, None) == -1
+    # p > 0 that quantises to 0 is an error, never a silent "no dropout"; offsets need one 32-bit counter word
+    assert L.fa_fwd_dropout(p, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, 0.001, 1, 0, None) == -2 and b"1/512" in L.fa_last_error()
+    assert L.fa_fwd_dropout(p, p, p, p, p, 1, 1, 8, 8, 64, 1, 0, 0.125, 0.1, 1, 1 << 32, None) == -2 and b"2^32" in L.fa_last_error()
     assert L.fa_bwd_dq_dropout(p, p, p, p, p, p, p, p, 1, 1, 8, 8, 96, 1, 0, 0.125, 0.1, 1, 0, None) == -3
     assert L.fa_bwd_dkv_dropout(p, p, p, p, p, p, p, p + 2, 1, 1, 8, 8, 64, 1, 0, 0.125, 0.1, 1, 0, None) == -5
     assert abs(L.fa_dropout_keep_scale(0.25) - 256.0 / 192.0) < 1e-6 and L.fa_dropout_keep_scale(0.0) == 1.0
@@ -166,7 +169,10 @@ def test_varlen_argument_errors_are_rejected_before_launch():
     tail = (2, 4, 100, 100, 64, 64, 64, 1, 0, 0.125, None)   # batch, H, total_q, total_k, max_q, max_k, D, dtype, causal, scale, stream
     assert L.fa_fwd_varlen(p, p, p, p, p, None, p, *tail) == -1 and b"cu_seqlens" in L.fa_last_error()
     assert L.fa_fwd_varlen(None, p, p, p, p, p, p, *tail) == -1
-    assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 100, 100, 200, 64, 64, 1, 0, 0.125, None) == -2    # max_q > total_q
+    assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 0, 100, 64, 64, 64, 1, 0, 0.125, None) == -2      # no query tokens
+    assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 100, 100, 0, 64, 64, 1, 0, 0.125, None) == -2     # max_seqlen_q < 1
+    # (max_seqlen above the token count is a legal static bound: ADVICE r2 -- only the 2^31-byte limit applies)
+    assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 100, 100, 1 << 23, 64, 64, 1, 0, 0.125, None) == -2
     assert L.fa_fwd_varlen(p, p, p, p, p, p, p, 2, 4, 100, 100, 64, 64, 96, 1, 0, 0.125, None) == -3     # head dim
     assert L.fa_bwd_dq_varlen(p, p, p, p, p, p, p, p, p, p + 4, 2, 4, 100, 100, 64, 64, 64, 7, 0, 0.125, None) == -4
     assert L.fa_bwd_dkv_varlen(p, p, p, p, p, p, p, p + 2, p, p, *tail) == -5
