@@ -372,6 +372,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       for (int s = 0; s < 16; ++s) {
         hook(I, s, 0);
         // ---- the MFMA of this slot ----
+#ifdef FA_DKV3_BUILTIN_MFMA   // diagnostic: compiler-visible MFMAs for the S / dP chains (results land in AGPRs: slow)
+        if (s < 4) {
+          const f32x16 zero = {};
+          S_[g] = T::mfma(as_vec8<T>(RF[s]), as_vec8<T>(kf[g][s]), s == 0 ? (FOLD ? NL[0] : zero) : S_[g]);
+        } else if (s < 8) {
+          P_[g] = T::mfma(as_vec8<T>(RF[s]), as_vec8<T>(vf[g][s - 4]), s == 4 ? ND : P_[g]);
+        } else if (s < 12) {
+#else
         if (s == 0) {
           if constexpr (FOLD) T::mfma_v_first(S_[g], RF[0], kf[g][0], NL[FOLD ? 0 : (qb & 1)]);
           else T::mfma_v_first0(S_[g], RF[0], kf[g][0]);
@@ -381,7 +389,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
           T::mfma_v_first(P_[g], RF[4], vf[g][0], ND);
         } else if (s < 8) {
           T::mfma_v_acc(P_[g], RF[s], vf[g][s - 4]);
-        } else if (s < 12) {   // (k-step e, d block db) = (n >> 1, n & 1): pk[0] is complete first
+        } else if (s < 12) {
+#endif   // (k-step e, d block db) = (n >> 1, n & 1): pk[0] is complete first
           const int n = s - 8, e = n >> 1, db = n & 1;
           dvacc[pg][db] = T::mfma(TF[2 * db + e], as_vec8<T>(pk[e]), dvacc[pg][db]);
         } else {
@@ -415,6 +424,13 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         }
         // ---- VALU of the previous block ----
         prev_valu(s, S_[pg], P_[pg], NL[FOLD ? 0 : ((g == 0 ? qb + 1 : qb) & 1)]);
+        // An MFMA reads its C operand over its passes: a VALU write to those registers within ~13 wait states corrupts
+        // it (hipcc pads this WAR hazard for its own MFMAs, not for an asm statement).  In the second key group's
+        // iteration the row constants are DEAD after the chain start that reads them (slot 0 / slot 4) until their
+        // reload, so hipcc reuses their registers for exp results at once -- seen as run-to-run differences in dK of
+        // the second key group only.  Keep them live for one more slot.
+        if (g == 1 && s == 1 && FOLD) keep_live(NL[0]);
+        if (g == 1 && s == 5) keep_live(ND);
         __builtin_amdgcn_sched_barrier(0);
       }
 #ifdef FA_STAMPS

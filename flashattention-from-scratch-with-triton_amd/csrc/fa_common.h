@@ -99,6 +99,10 @@ template <typename A4> FA_DEVINL void BF16::mfma_v_acc(f32x16& d, u32x4 a, A4 b)
 template <typename A4> FA_DEVINL void FP16::mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c) { mfma_v_f16_first(d, a, b, c); }
 template <typename A4> FA_DEVINL void FP16::mfma_v_first0(f32x16& d, u32x4 a, A4 b) { mfma_v_f16_first0(d, a, b); }
 template <typename A4> FA_DEVINL void FP16::mfma_v_acc(f32x16& d, u32x4 a, A4 b) { mfma_v_f16_acc(d, a, b); }
+// `x` stays in its registers up to this point (an empty asm that reads it).  A __device__ function on purpose: an asm
+// statement with an AMDGPU register constraint written directly in a __global__ body makes the HOST pass drop the
+// kernel's stub without a diagnostic (undefined symbol at load time).
+FA_DEVINL void keep_live(const f32x16& x) { asm volatile("" ::"v"(x)); }
 // a 128-bit value moved into accumulator registers (explicitly: a value DEFINED in AGPRs needs no copy at its uses)
 FA_DEVINL agpr4_t to_agpr(u32x4 v) {
 #if !FA_MFMA_B_AGPR

@@ -8,6 +8,9 @@ kind of A/B that means anything on a DVFS-limited part.
 
     python tools/kbench.py [--libs a.so,b.so] [--rounds 7] [--reps 10] [--dim 64] [--dtype bf16]
                            [--seq 4096] [--kernels fwd,dq,dkv] [--non-causal] [--warm-ms 300]
+
+An arm may pin its schedule families: `--libs libmi355fa.so@0,0,2,libmi355fa.so@0,0,3` compares two families of ONE build
+(the forced families are set before every launch of that arm).
 """
 import argparse
 import ctypes
@@ -39,19 +42,29 @@ ap.add_argument("--impl", default="", help="force schedule family per kernel: fw
 a = ap.parse_args()
 
 
-def load(path):
+def load(spec):
+    path, _, impl = spec.partition("@")
     lib = ctypes.CDLL(path if os.path.isabs(path) else os.path.join(ROOT, path))
     for name, (res, args) in host.SIGNATURES.items():
         if not hasattr(lib, name):   # an older A/B build (e.g. before the strided entry points)
             continue
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if a.impl and hasattr(lib, "fa_debug_force_impl"):
-        lib.fa_debug_force_impl(*[int(x) for x in a.impl.split(",")])
-    return lib
+    forced = [int(x) for x in (impl or a.impl).split(",")] if (impl or a.impl) else None
+    return lib, forced
 
 
-libs = [(os.path.basename(p), load(p)) for p in a.libs.split(",")]
+def split_libs(text):   # "a.so@0,0,2,b.so" -> ["a.so@0,0,2", "b.so"]: a comma starts a new arm when a path follows it
+    out = []
+    for tok in text.split(","):
+        if out and tok.strip().lstrip("-").isdigit():
+            out[-1] += "," + tok
+        else:
+            out.append(tok)
+    return out
+
+
+libs = [(os.path.basename(p), load(p)) for p in split_libs(a.libs)]
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 code = host.BF16 if a.dtype == "bf16" else host.FP16
 causal = not a.non_causal
@@ -66,7 +79,17 @@ c, sc = int(causal), D ** -0.5
 P = lambda t: t.data_ptr()
 
 
-def fns(lib):
+def fns(lib_forced):
+    lib, forced = lib_forced
+    if forced is not None:
+        plain = fns((lib, None))
+
+        def pinned(f):
+            def go():
+                lib.fa_debug_force_impl(*forced)
+                return f()
+            return go
+        return {k: pinned(v) for k, v in plain.items()}
     return {
         "fwd": lambda: lib.fa_fwd(P(Q), P(K), P(V), P(O), P(LSE), B, H, S, S, D, code, c, sc, st),
         "dq": lambda: lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, code, c, sc, st),
