@@ -16,8 +16,8 @@
 //     slots 4-7   dP = dO V^T         of block i     (chain starts from -delta)
 //     slots 8-11  dV^T += dO^T P      of block i-1
 //     slots 12-15 dK^T += Q^T dS      of block i-1
-//   and beside the MFMAs, per slot: two exp + one pack of block i-1 (slots 0-7), three dS multiplies + packs (slots
-//   8-13), the LDS reads of fragments and row constants whose registers have just become free (each is read >= 4 slots before
+//   and beside the MFMAs, per slot: ONE exp, one dS multiply and one pack (block i from its slot 5 on, block i-1 until
+//   its work is done at slot 10 -- block_valu() below), the LDS reads of fragments and row constants whose registers have just become free (each is read >= 4 slots before
 //   its first use and kept for its second use 16 slots later), one LDS-DMA piece of the next tile in some dK slots,
 //   closed by sched_barrier(0) so that hipcc keeps exactly this order.
 //   The per-tile commit (vmcnt(0), row constants -> LDS, s_barrier) sits INSIDE iteration 7, after the last read of the
@@ -51,16 +51,23 @@ struct Dkv3Cfg {
   static constexpr int RPI = 1024 / ROWB;                  // tile rows per 1-KiB DMA piece
 };
 
-// where the 8 LDS-DMA pieces of the NEXT tile (0-3 Q, 4-7 dO rows of this wave's 32-row share) are issued: block
-// iteration and slot.  dK slots carry the least VALU work.  A/B hooks: -DFA_DKV3_DMA_ITERS / _SLOTS.
+// where the 8 LDS-DMA pieces of a coming tile (0-3 Q, 4-7 dO rows of this wave's 32-row share) are issued: block
+// iteration and slot.  The commit inside iteration 7 of tile t frees tile t's own buffer, so a piece placed in iteration 7
+// (slot >= 5) already belongs to tile t + 2; pieces in iterations 0-6 of tile t + 1 complete that tile.  Everything
+// is waited for by the next commit (vmcnt(0)), a whole tile time after the first piece.  A/B hooks: -DFA_DKV3_DMA_ITERS / _SLOTS.
 #ifndef FA_DKV3_DMA_ITERS
-#define FA_DKV3_DMA_ITERS {0, 0, 1, 1, 2, 2, 3, 3}
+#define FA_DKV3_DMA_ITERS {7, 7, 7, 7, 0, 0, 0, 0}
 #endif
 #ifndef FA_DKV3_DMA_SLOTS
-#define FA_DKV3_DMA_SLOTS {13, 15, 13, 15, 13, 15, 13, 15}
+#define FA_DKV3_DMA_SLOTS {9, 11, 13, 15, 9, 11, 13, 15}
 #endif
 constexpr int kDkv3DmaIter[8] = FA_DKV3_DMA_ITERS;
 constexpr int kDkv3DmaSlot[8] = FA_DKV3_DMA_SLOTS;
+// pieces issued together (one M0 write, consecutive immediates): group k = pieces [k G, k G + G) takes piece k G's place
+#ifndef FA_DKV3_DMA_GROUP
+#define FA_DKV3_DMA_GROUP 2   // A/B at the headline: 2 per group +0.7 % (non-causal) / +1.2 % (causal) over single pieces, 4 the same
+#endif
+constexpr int kDkv3DmaGroup = FA_DKV3_DMA_GROUP;
 
 #ifdef FA_STAMPS
 #define FA3_STAMP(slot)                                                           \
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
 #ifdef FA_STAMPS
   unsigned long long clk0_, rt0_;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long seg[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = 0, nblk_ = 0;
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -138,8 +145,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
   for (int i = 0; i < C::DMA_PER_MAT; ++i) {
     const int row = (C::BQ / C::NW) * wave + C::RPI * i + lane / C::CPR;
     const int chunk = swz_chunk<D>(row, lane % C::CPR) * 16;
-    dma_q[i] = row * q_rs + chunk;
-    dma_do[i] = row * do_rs + chunk;
+    // (piece i of a group carries the immediate offset 1024 * (i % G), which also moves the global address: taken out here)
+    dma_q[i] = row * q_rs + chunk - 1024 * (i % kDkv3DmaGroup);
+    dma_do[i] = row * do_rs + chunk - 1024 * (i % kDkv3DmaGroup);
   }
   int row_off[C::KS];
 #pragma unroll
@@ -166,15 +174,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
     if (pass) __syncthreads();  // the previous pass staged dK / dV in the tile buffers
 
     const int t_start = CAUSAL ? k0_wg / C::BQ : 0;
-    const int t_diag_end = CAUSAL ? min(ntiles, t_start + C::BK / C::BQ) : 0;  // tiles level with the key tile
+    const int t_diag_end = CAUSAL ? min(ntiles, t_start + C::BK / C::BQ + 1) : 0;  // tiles run with the causal mask
 
     // ---- DMA of one Q/dO tile + the row-constant load (one float per thread) ----
     float rc = 0.f;
-    auto dma_piece = [&](int t, int buf, int j) __attribute__((always_inline)) {  // j: 0-3 Q, 4-7 dO
+    auto dma_piece = [&](int t, int buf, int j) __attribute__((always_inline)) {  // j: 0-3 Q, 4-7 dO; the group led by j
+      if (j % kDkv3DmaGroup != 0) return;
       const int i = j & 3;
       const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * i) * C::ROWB;
-      if (j < 4) dma_pieces<1>(rq, lds_addr_of(smem + dst), dma_q + i, t * C::BQ * q_rs);
-      else dma_pieces<1>(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_do + i, t * C::BQ * do_rs);
+      if (j < 4) dma_pieces<kDkv3DmaGroup>(rq, lds_addr_of(smem + dst), dma_q + i, t * C::BQ * q_rs);
+      else dma_pieces<kDkv3DmaGroup>(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_do + i, t * C::BQ * do_rs);
     };
     auto fetch_rc = [&](int t) __attribute__((always_inline)) { rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4); };
     auto fetch_tile = [&](int t, int buf) __attribute__((always_inline)) {
@@ -185,7 +194,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
     // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet
     auto commit_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
       asm volatile("" ::: "memory");
+#ifndef FA_DKV3_NO_VMWAIT   // (timing ablations only: results are wrong without the wait / the barrier)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
       if (fetched) {
         FA_LDS float* rcp = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
         // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
@@ -193,7 +204,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         rcp[tid] = rc_lse ? lse_c : -rc;  // rcp[row] = -LSE*log2e, rcp[BQ + row] = -delta
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the ds_write above and every LDS read issued so far
+#ifndef FA_DKV3_NO_BARRIER
       __builtin_amdgcn_s_barrier();
+#endif
+#ifdef FA_DKV3_SKEW   // A/B hook: wave w leaves the barrier w * FA_DKV3_SKEW s_nop-15 groups late (de-phases the waves' DMA issue)
+      wave_skew(wave);
+#endif
       asm volatile("" ::: "memory");
     };
 
@@ -223,83 +239,20 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
           dvacc[g][db][i] = 0.f;
         }
 
-    // ---- simple path (diagonal region): one 32-row query block x one 32-key group, compiler-scheduled ----
-    auto q_block = [&](int buf, int b, int g, int qb0, auto masked_tag) __attribute__((always_inline)) {
-      constexpr bool MASKED = decltype(masked_tag)::value;
-      const FA_LDS char* qbp = smem + buf * C::TILE_BYTES + b * 32 * C::ROWB;
-      const FA_LDS char* dbp = smem + C::DO_BASE + buf * C::TILE_BYTES + b * 32 * C::ROWB;
-      const FA_LDS char* rcp = smem + C::ROWC_OFF + buf * C::ROWC_BYTES;
-      f32x16 nl, pacc, sacc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {  // per-register row constants: reg i <-> row (i&3) + 8(i>>2) + 4h
-        const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * q + 4 * h) * 4);
-        const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * q + 4 * h) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          nl[4 * q + j] = a[j];
-          sacc[4 * q + j] = FOLD ? a[j] : 0.f;
-          pacc[4 * q + j] = d[j];
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) T::mfma_v_acc(sacc, lds_read16(qbp + row_off[ks]), kf[g][ks]);
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) T::mfma_v_acc(pacc, lds_read16(dbp + row_off[ks]), vf[g][ks]);
-      // asm MFMA results -> VALU readers: 12 wait states that hipcc does not insert for an asm statement
-      asm volatile("s_nop 15" : "+v"(sacc), "+v"(pacc));
-      vec8 dof[C::DB][2], qtf[C::DB][2];
-#pragma unroll
-      for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          dof[db][e] = lds_read_tr_frag<T>(dbp + 16 * e * C::ROWB + tr_off[0][db], dbp + 16 * e * C::ROWB + tr_off[1][db]);
-          qtf[db][e] = lds_read_tr_frag<T>(qbp + 16 * e * C::ROWB + tr_off[0][db], qbp + 16 * e * C::ROWB + tr_off[1][db]);
-        }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float x = FOLD ? sacc[i] : __builtin_fmaf(sacc[i], c2, nl[i]);
-        if constexpr (MASKED) {
-          const int qrow = qb0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          x = (kw[g] + r > qrow) ? -INFINITY : x;
-        }
-        const float pe = __builtin_amdgcn_exp2f(x);
-        sacc[i] = pe;            // P
-        pacc[i] = pe * pacc[i];  // dS = P o (dP - delta)
-      }
-      const vec8 p0 = pack8<T, 0>(sacc), p1 = pack8<T, 1>(sacc);
-      const vec8 s0 = pack8<T, 0>(pacc), s1 = pack8<T, 1>(pacc);
-#pragma unroll
-      for (int db = 0; db < C::DB; ++db) {
-        dvacc[g][db] = T::mfma(dof[db][0], p0, dvacc[g][db]);
-        dvacc[g][db] = T::mfma(dof[db][1], p1, dvacc[g][db]);
-        dkacc[g][db] = T::mfma(qtf[db][0], s0, dkacc[g][db]);
-        dkacc[g][db] = T::mfma(qtf[db][1], s1, dkacc[g][db]);
-      }
-    };
-    auto step_simple = [&](int t) __attribute__((always_inline)) {
-      const int buf = t & 1;
-      const bool more = t + 1 < ntiles;
-      if (more) fetch_tile(t + 1, buf ^ 1);
-      for (int b = 0; b < C::QB; ++b) {
-        const int qb0 = t * C::BQ + 32 * b;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if (qb0 < kw[g]) continue;  // every row of the block is above the diagonal of this key group
-          if (qb0 == kw[g]) q_block(buf, b, g, qb0, std::true_type{});
-          else q_block(buf, b, g, qb0, std::false_type{});
-        }
-      }
-      commit_tile(t + 1, buf ^ 1, more);
-    };
-
-    // ---- the pipeline (unmasked tiles): state carried from block to block, tile to tile ----
+    // ---- the pipeline: state carried from block to block, tile to tile ----
     f32x16 S_[2], P_[2];   // [key group]: score / dP accumulators of the block in flight; the OTHER set holds the
                            // previous block's exponent arguments -> P and dP - delta -> dS
     f32x16 NL[FOLD ? 1 : 2], ND;      // row constants of a query block ([query block parity] for NL: the exact-fma path (fp16)
                            // needs the previous block's -LSE*log2e while the next block's is being read)
     u32x4 RF[8];           // row fragments of the current query block: Q k-steps 0-3, dO k-steps 0-3
     vec8 TF[8];            // transposed fragments of the previous block's query block: dO^T (db, e) 0-3, Q^T 4-7
-    u32x4 pk[2], sk[2];    // packed P and dS of the previous block, k-steps 0 / 1
+    u32x4 pk[2][2], sk[2][2];   // [key group][k-step]: packed P and dS of a block (written while the other set is read)
+    // causal mask of a block, one comparison per element: the score in register i of lane (r, h) belongs to key kw[g] + r
+    // and query row qb0 + c_i + 4h with c_i = (i & 3) + 8 (i >> 2); it is dead iff  thr = kw[g] - qb0 + r - 4h  >  c_i.
+    // A block entirely below the diagonal has thr < 0 (nothing masked), one entirely above it thr >= 32 (everything): the
+    // same formula serves the three tiles level with the key tile, whatever a wave's key groups see of them.
+    int thr[2] = {0, 0};
+    const int lane_thr = r - 4 * h;
     auto rowc_read = [&](const FA_LDS char* rcp, int b, int q, f32x16& nl, f32x16& nd) __attribute__((always_inline)) {
       const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * q + 4 * h) * 4);
       const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * q + 4 * h) * 4);
@@ -309,16 +262,25 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         nd[4 * q + j] = d[j];
       }
     };
-    // fill: the first iteration's "previous block" is neutral (P = exp2(-inf) = 0, dS = 0 * 0, fragments 0)
-    auto pipe_fill = [&](int buf) __attribute__((always_inline)) {
+    // fill: the first iteration's "previous block" is neutral (P = 0, dS = 0 * 0, packed P / dS and fragments 0)
+    auto pipe_fill = [&](int t, int buf) __attribute__((always_inline)) {
+      // the pieces a previous tile step would have issued in its iteration 7 (nothing of tile t + 1 is in flight yet)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (kDkv3DmaIter[j] == C::NI - 1) dma_piece(t + 1, buf ^ 1, j);
       const FA_LDS char* qt = smem + buf * C::TILE_BYTES;
       const FA_LDS char* dt = smem + C::DO_BASE + buf * C::TILE_BYTES;
       const FA_LDS char* rcp = smem + C::ROWC_OFF + buf * C::ROWC_BYTES;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        S_[1][i] = -INFINITY;
-        P_[1][i] = 0.f;
+        S_[1][i] = i < 11 ? 0.f : -INFINITY;   // block_valu: exps 0-10 of a block are over when its iteration ends (P = 0),
+        P_[1][i] = 0.f;                        // exps 11-15 follow (exp2(-inf) = 0); dS = 0 * 0
         if (!FOLD) NL[FOLD ? 0 : 1][i] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        pk[1][e] = u32x4{0u, 0u, 0u, 0u};
+        sk[1][e] = u32x4{0u, 0u, 0u, 0u};
       }
 #pragma unroll
       for (int n = 0; n < 8; ++n) TF[n] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
@@ -331,35 +293,41 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       for (int q = 0; q < 4; ++q) rowc_read(rcp, 0, q, NL[0], ND);
       __builtin_amdgcn_sched_barrier(0);
     };
-    // VALU work of the previous block under slot s (X = its exponent arguments -> P, Y = dP - delta -> dS)
-    auto prev_valu = [&](int s, f32x16& X, f32x16& Y, const f32x16& nlp) __attribute__((always_inline)) {
-      if (s < 8) {
-#pragma unroll
-        for (int e = 2 * s; e < 2 * s + 2; ++e)
-          X[e] = __builtin_amdgcn_exp2f(FOLD ? X[e] : __builtin_fmaf(X[e], c2, nlp[e]));
+    // VALU work of ONE block at pipeline time tau = slots since the start of the block's own iteration.  A block's 16
+    // exps, 16 dS multiplies and 16 packs are spread over 22 slots, one of each kind per slot (the guide's rule for one
+    // wave per SIMD: at most one transcendental among <= 5 fillers per MFMA gap; two exps per gap, as family 2 places
+    // them, do not hide):   exp e at tau = 5 + e      (the S chain ended at slot 3: past the MFMA -> VALU wait states)
+    //                       pack P pair j at 7 + 2j   (pk complete at 21 = slot 5 of the next iteration; read from slot 8)
+    //                       dS e at tau = 10 + e      (the dP chain ended at slot 7)
+    //                       pack dS pair j at 12 + 2j (sk complete at 26 = slot 10 of the next iteration; read from slot 12)
+    // so every slot carries tau = s of the block in flight and tau = 16 + s of the previous one.
+    auto block_valu = [&](int tau, f32x16& X, f32x16& Y, u32x4 (&pkb)[2], u32x4 (&skb)[2], const f32x16& nl, auto mask_tag,
+                          int thr_b) __attribute__((always_inline)) {
+      constexpr bool MASK = decltype(mask_tag)::value;
+      const int e = tau - 5, m = tau - 10;
+      if (e >= 0 && e < 16) {
+        float x = FOLD ? X[e] : __builtin_fmaf(X[e], c2, nl[e]);
+        if constexpr (MASK) x = thr_b > (e & 3) + 8 * (e >> 2) ? -INFINITY : x;
+        X[e] = __builtin_amdgcn_exp2f(x);
       }
-      if (s >= 1 && s <= 8) {
-        const int j = s - 1;
-        pk[j >> 2][j & 3] = pack2<T>(X[2 * j], X[2 * j + 1]);
+      if (m >= 0 && m < 16) Y[m] = X[m] * Y[m];
+      if (tau >= 7 && tau <= 21 && ((tau - 7) & 1) == 0) {
+        const int j = (tau - 7) >> 1;
+        pkb[j >> 2][j & 3] = pack2<T>(X[2 * j], X[2 * j + 1]);
       }
-      // dS multiplies: 3 per slot under the dV slots, the last 4 under the first dK slot; each pair is packed as soon as
-      // both its products exist (sk[0] = pairs 0-3 is read by slot 12, sk[1] = pairs 4-7 by slot 14)
-      constexpr int m0[6] = {0, 3, 6, 9, 12, 16}, m1[6] = {3, 6, 9, 12, 16, 16};
-      constexpr int c0[6] = {0, 1, 3, 4, 6, 7}, c1[6] = {1, 3, 4, 6, 7, 8};
-      if (s >= 8 && s <= 13) {
-#pragma unroll
-        for (int e = m0[s - 8]; e < m1[s - 8]; ++e) Y[e] = X[e] * Y[e];
-#pragma unroll
-        for (int j = c0[s - 8]; j < c1[s - 8]; ++j) sk[j >> 2][j & 3] = pack2<T>(Y[2 * j], Y[2 * j + 1]);
+      if (tau >= 12 && tau <= 26 && ((tau - 12) & 1) == 0) {
+        const int j = (tau - 12) >> 1;
+        skb[j >> 2][j & 3] = pack2<T>(Y[2 * j], Y[2 * j + 1]);
       }
     };
     // one block iteration; I = 2 * query block + key group.  `qt` / `dt` / `rct`: current tile; `qn` / `dn` / `rcn`: next
     // tile (read from iteration 7, slot 4 on -- after the commit).  `hook(I, s, 0)` runs before the slot's MFMA (the
     // commit), `hook(I, s, 1)` right after it (LDS-DMA pieces: their issue then overlaps the MFMA just started).
-    auto block_iter = [&](auto i_tag, const FA_LDS char* qt, const FA_LDS char* dt, const FA_LDS char* rct,
-                          const FA_LDS char* qn, const FA_LDS char* dn, const FA_LDS char* rcn,
+    auto block_iter = [&](auto i_tag, auto mask_tag, int row0, const FA_LDS char* qt, const FA_LDS char* dt,
+                          const FA_LDS char* rct, const FA_LDS char* qn, const FA_LDS char* dn, const FA_LDS char* rcn,
                           auto&& hook) __attribute__((always_inline)) {
       constexpr int I = decltype(i_tag)::value;
+      if constexpr (decltype(mask_tag)::value) thr[I & 1] = lane_thr + (kw[I & 1] - row0 - 32 * (I >> 1));
       constexpr int qb = I >> 1, g = I & 1, pg = g ^ 1;     // pg: key group of the previous block
       constexpr bool last_qb = qb + 1 == C::QB;
       constexpr int nqb = last_qb ? 0 : qb + 1;              // next query block (block 0 of the next tile after the last)
@@ -392,10 +360,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         } else if (s < 12) {
 #endif   // (k-step e, d block db) = (n >> 1, n & 1): pk[0] is complete first
           const int n = s - 8, e = n >> 1, db = n & 1;
-          dvacc[pg][db] = T::mfma(TF[2 * db + e], as_vec8<T>(pk[e]), dvacc[pg][db]);
+          dvacc[pg][db] = T::mfma(TF[2 * db + e], as_vec8<T>(pk[pg][e]), dvacc[pg][db]);
         } else {
           const int n = s - 12, e = n >> 1, db = n & 1;
-          dkacc[pg][db] = T::mfma(TF[4 + 2 * db + e], as_vec8<T>(sk[e]), dkacc[pg][db]);
+          dkacc[pg][db] = T::mfma(TF[4 + 2 * db + e], as_vec8<T>(sk[pg][e]), dkacc[pg][db]);
         }
         hook(I, s, 1);
         // ---- LDS reads into registers that have just become free ----
@@ -422,8 +390,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
             }
           }
         }
-        // ---- VALU of the previous block ----
-        prev_valu(s, S_[pg], P_[pg], NL[FOLD ? 0 : ((g == 0 ? qb + 1 : qb) & 1)]);
+        // ---- VALU: the previous block at tau = 16 + s, this block at tau = s ----
+        block_valu(16 + s, S_[pg], P_[pg], pk[pg], sk[pg], NL[FOLD ? 0 : ((g == 0 ? qb + 1 : qb) & 1)], mask_tag, thr[pg]);
+        block_valu(s, S_[g], P_[g], pk[g], sk[g], NL[FOLD ? 0 : (qb & 1)], mask_tag, thr[g]);
         // An MFMA reads its C operand over its passes: a VALU write to those registers within ~13 wait states corrupts
         // it (hipcc pads this WAR hazard for its own MFMAs, not for an asm statement).  In the second key group's
         // iteration the row constants are DEAD after the chain start that reads them (slot 0 / slot 4) until their
@@ -434,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
 #ifdef FA_STAMPS
-      FA3_STAMP(1);
+      FA3_STAMP(I);   // seg[0..7]: block iteration I of a tile (iteration 7 without its commit)
       ++nblk_;
 #endif
     };
@@ -444,16 +413,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       for (int s = 0; s < 16; ++s) {
         if (s >= 8 && s < 12) {
           const int n = s - 8, e = n >> 1, db = n & 1;
-          dvacc[1][db] = T::mfma(TF[2 * db + e], as_vec8<T>(pk[e]), dvacc[1][db]);
+          dvacc[1][db] = T::mfma(TF[2 * db + e], as_vec8<T>(pk[1][e]), dvacc[1][db]);
         } else if (s >= 12) {
           const int n = s - 12, e = n >> 1, db = n & 1;
-          dkacc[1][db] = T::mfma(TF[4 + 2 * db + e], as_vec8<T>(sk[e]), dkacc[1][db]);
+          dkacc[1][db] = T::mfma(TF[4 + 2 * db + e], as_vec8<T>(sk[1][e]), dkacc[1][db]);
         }
-        prev_valu(s, S_[1], P_[1], NL[FOLD ? 0 : ((C::QB - 1) & 1)]);
+        block_valu(16 + s, S_[1], P_[1], pk[1], sk[1], NL[FOLD ? 0 : ((C::QB - 1) & 1)], std::integral_constant<bool, CAUSAL>{}, thr[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto step_pipe = [&](int t, int buf) __attribute__((always_inline)) {
+    auto step_pipe = [&](int t, int buf, auto mask_tag) __attribute__((always_inline)) {
       const bool more = t + 1 < ntiles;
       const FA_LDS char* qt = smem + buf * C::TILE_BYTES;
       const FA_LDS char* dt = smem + C::DO_BASE + buf * C::TILE_BYTES;
@@ -470,26 +439,27 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       auto hook = [&](int I, int s, int phase) __attribute__((always_inline)) {
         if (phase == 0) {
           if (I == C::NI - 1 && s == 4) {   // every read of this tile's buffers is issued: hand the other buffer over
-            FA3_STAMP(2);
+            FA3_STAMP(7);
             commit_tile(t + 1, buf ^ 1, true);
-            FA3_STAMP(3);
+            FA3_STAMP(8);   // seg[8]: the commit (vmcnt(0), row constants, lgkmcnt(0), barrier)
           }
           return;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (kDkv3DmaIter[j] == I && kDkv3DmaSlot[j] == s) {
-            dma_piece(t + 1, buf ^ 1, j);
+            if (I == C::NI - 1) dma_piece(t + 2, buf, j);   // after this tile's commit: its own buffer is free
+            else dma_piece(t + 1, buf ^ 1, j);
           }
       };
-      block_iter(std::integral_constant<int, 0>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 1>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 2>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 3>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 4>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 5>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 6>{}, qt, dt, rct, qn, dn, rcn, hook);
-      block_iter(std::integral_constant<int, 7>{}, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 0>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 1>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 2>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 3>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 4>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 5>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 6>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      block_iter(std::integral_constant<int, 7>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
     };
 
 #ifdef FA_STAMPS
@@ -497,14 +467,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
 #endif
     commit_tile(t_start, t_start & 1, t_start < ntiles);  // first tile landed (and the K/V fragments)
     int t = t_start;
-    for (; t < t_diag_end; ++t) step_simple(t);
-    FA3_STAMP(0);
     if (t < ntiles) {
-      pipe_fill(t & 1);
-      for (; t < ntiles; ++t) step_pipe(t, t & 1);
+      pipe_fill(t, t & 1);
+      FA3_STAMP(10);  // seg[10]: pipeline fill
+      // the tiles level with the key tile (and one more, so that the last masked block has left the pipeline): masked
+      for (; t < t_diag_end; ++t) step_pipe(t, t & 1, std::true_type{});
+      FA3_STAMP(9);   // seg[9]: (causal) the masked tiles
+      for (; t < ntiles; ++t) step_pipe(t, t & 1, std::false_type{});
       pipe_drain();
     }
-    FA3_STAMP(4);
+    FA3_STAMP(11);    // seg[11]: drain
 
     __syncthreads();  // every wave is done with the tile buffers: they become the staging area
     FA_LDS char* stage = smem + wave * 32 * C::ROWB;
@@ -515,17 +487,17 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       store_tile_rows<D, T>(dkacc[g], dk_mul, stage, rdk, kw[g] * dk_rs, lane, dk_rs);
       store_tile_rows<D, T>(dvacc[g], 1.0f, stage, rdv, kw[g] * dv_rs, lane, dv_rs);
     }
-    FA3_STAMP(5);
+    FA3_STAMP(12);    // seg[12]: epilogue
   }  // pass
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {
-    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-    for (int i = 0; i < 8; ++i) d[i] = seg[i];
-    d[8] = nblk_;
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 16;
+    for (int i = 0; i < 13; ++i) d[i] = seg[i];
+    d[13] = nblk_;
     unsigned long long clk1_, rt1_;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_)::"memory");
-    d[9] = clk1_ - clk0_;
-    d[10] = rt1_ - rt0_;
+    d[14] = clk1_ - clk0_;
+    d[15] = rt1_ - rt0_;
   }
 #endif
 }

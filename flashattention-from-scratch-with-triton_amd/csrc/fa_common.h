@@ -103,6 +103,19 @@ template <typename A4> FA_DEVINL void FP16::mfma_v_acc(f32x16& d, u32x4 a, A4 b)
 // statement with an AMDGPU register constraint written directly in a __global__ body makes the HOST pass drop the
 // kernel's stub without a diagnostic (undefined symbol at load time).
 FA_DEVINL void keep_live(const f32x16& x) { asm volatile("" ::"v"(x)); }
+#ifdef FA_DKV3_SKEW
+#define FA_SKEW_NOPS_1 "s_nop 15\n\t"
+#define FA_SKEW_NOPS_2 "s_nop 15\n\ts_nop 15\n\t"
+#define FA_SKEW_NOPS_4 "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+#define FA_SKEW_CAT_(n) FA_SKEW_NOPS_##n
+#define FA_SKEW_CAT(n) FA_SKEW_CAT_(n)
+FA_DEVINL void wave_skew(int wave) {
+  asm volatile("s_cmp_lt_u32 %0, 1\n\ts_cbranch_scc1 L_skew%=\n\t" FA_SKEW_CAT(FA_DKV3_SKEW)
+               "s_cmp_lt_u32 %0, 2\n\ts_cbranch_scc1 L_skew%=\n\t" FA_SKEW_CAT(FA_DKV3_SKEW)
+               "s_cmp_lt_u32 %0, 3\n\ts_cbranch_scc1 L_skew%=\n\t" FA_SKEW_CAT(FA_DKV3_SKEW)
+               "L_skew%=:" ::"s"(wave) : "scc");
+}
+#endif
 // a 128-bit value moved into accumulator registers (explicitly: a value DEFINED in AGPRs needs no copy at its uses)
 FA_DEVINL agpr4_t to_agpr(u32x4 v) {
 #if !FA_MFMA_B_AGPR

@@ -24,7 +24,7 @@ TABLE_H = os.path.join(PKG, "csrc", "fa_table.h")
 BH_BUCKETS = [8, 32, 128, 512]                                  # B*H, nearest in log2
 S_BUCKETS = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]      # max(S_q, S_k), nearest in log2
 KERNELS = ["fwd", "dq", "dkv"]
-CANDIDATES = {"fwd": {64: [1, 2, 3], 128: [1]}, "dq": {64: [1, 2, 3], 128: [1]}, "dkv": {64: [1, 2], 128: [1, 2]}}
+CANDIDATES = {"fwd": {64: [1, 2, 3], 128: [1]}, "dq": {64: [1, 2, 3], 128: [1]}, "dkv": {64: [1, 2, 3], 128: [1, 2]}}
 DTYPES = ["fp16", "bf16"]
 
 
@@ -39,7 +39,7 @@ def rule_family(kernel, D, dtype, causal, bh, S):
     return 2 if (not causal and wgs2 >= 512) else 1
 
 
-def measure(out_path, rounds, reps, min_ms):
+def measure(out_path, rounds, reps, min_ms, only=None):
     sys.path.insert(0, PKG)
     import torch
     import _mi355fa as host
@@ -73,6 +73,8 @@ def measure(out_path, rounds, reps, min_ms):
                         lib.fa_debug_force_impl(0, 0, 0)
                         assert fns["fwd"]() == 0 and fns["dq"]() == 0      # valid O / LSE / delta for the timed launches
                         for ki, kern in enumerate(KERNELS):
+                            if only and kern not in only:
+                                continue
                             cands = CANDIDATES[kern][D]
                             times = {c: [] for c in cands}
                             # launches per timing: at least `min_ms` of back-to-back work (estimated at ~1 PFLOP/s), so that
@@ -173,9 +175,20 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=2000)
     ap.add_argument("--min-ms", type=float, default=10.0, help="back-to-back work per timing (sustained clocks)")
+    ap.add_argument("--kernels", default="", help="measure only these kernels (comma list of fwd,dq,dkv); --merge-into keeps the rest")
+    ap.add_argument("--merge-into", default="", help="with --measure: start from this older measurement file and replace "
+                                                     "the points of the kernels measured now")
     a = ap.parse_args()
     if a.measure:
-        measure(a.measure, a.rounds, a.reps, a.min_ms)
+        only = [k for k in a.kernels.split(",") if k]
+        measure(a.measure, a.rounds, a.reps, a.min_ms, only)
+        if a.merge_into:
+            new = json.load(open(a.measure))
+            old = json.load(open(a.merge_into))
+            keep = [p for p in old["points"] if p["kernel"] not in (only or KERNELS)]
+            new["points"] = keep + new["points"]
+            json.dump(new, open(a.measure, "w"), indent=0)
+            print("merged %d older points of the other kernels from %s" % (len(keep), a.merge_into))
     if a.emit:
         emit(json.load(open(a.emit))["points"], os.path.relpath(a.emit, ROOT))
     if a.emit_rule:
