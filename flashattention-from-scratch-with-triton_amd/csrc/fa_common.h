@@ -116,6 +116,10 @@ FA_DEVINL void wave_skew(int wave) {
                "L_skew%=:" ::"s"(wave) : "scc");
 }
 #endif
+// the 12+ wait states between an asm MFMA's result and its first VALU reader (outside the pipelines, where the reader
+// follows at once); a __device__ function for the same host-pass reason as keep_live
+FA_DEVINL void settle_mfma(f32x16& x) { asm volatile("s_nop 15" : "+v"(x)); }
+FA_DEVINL void settle_mfma(f32x16& x, f32x16& y) { asm volatile("s_nop 15" : "+v"(x), "+v"(y)); }
 // a 128-bit value moved into accumulator registers (explicitly: a value DEFINED in AGPRs needs no copy at its uses)
 FA_DEVINL agpr4_t to_agpr(u32x4 v) {
 #if !FA_MFMA_B_AGPR

@@ -478,11 +478,13 @@ static hipError_t launch(const FwdParams& p, hipStream_t s) {
 
 hipError_t launch_fwd_v2(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v2.hip
 hipError_t launch_fwd_v3(FwdParams p, int dtype, int causal, hipStream_t s);  // fa_fwd_v3.hip
+hipError_t launch_fwd_v4(FwdParams p, int D, int dtype, int causal, hipStream_t s);  // fa_fwd_v4.hip
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
   const int impl = p.drop.thresh ? 1 : pick_fwd_impl(g_force_fwd, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, p.vl.cu_q == nullptr);
   if (impl == 2) return launch_fwd_v2(p, dtype, causal, s);
   if (impl == 3) return launch_fwd_v3(p, dtype, causal, s);
+  if (impl == 4) return launch_fwd_v4(p, D, dtype, causal, s);
   p.nq_tiles = (p.Sq + 127) / 128;
   p.pair = want_pairs(causal != 0, p.nq_tiles, (long)p.B * p.H);
 #define FA_GO(DD, TT)                                                                           \

@@ -1,0 +1,454 @@
+// FlashAttention forward, fourth schedule family for gfx950: ONE wave per SIMD, 64 query rows per wave, a continuous
+// hand-ordered software pipeline (head dim 64 and 128).
+//
+// Same maths as fa_fwd.hip (reference kernel code/_flash_attention_kernel_optimized.py:35-129: fp32 scores and softmax
+// state, P rounded to the input dtype for P @ V (K:115), O = o / l cast on store (K:120-123), LSE = m + ln l (K:126),
+// top-left aligned causal mask (K:102), keys >= S_k masked (K:94)); what differs is the schedule and ONE numerical
+// choice (below: the running maximum is not tracked, which changes nothing but the common scale of P, o and l).
+//
+// Why a fourth family.  The forward is bound by vector issue, not by the matrix pipe: per 32 x 64 score tile 16 MFMAs
+// (512 cycles) stand against 32 exp + 32 row-sum adds + 16 packs (~470 issue cycles) + the MFMAs' own issue (128).
+// Families 1-3 lose a further third to everything around that minimum: a barrier every 16 MFMAs, phases that do not
+// overlap inside a wave, a branch per tile for the lazy-maximum test, and LDS fragment reads that serve one 32-row block.
+// Here a workgroup is 256 query rows, a wave owns TWO 32-row blocks and
+//   * every K fragment (S^T = K Q^T) and every V^T fragment (O^T += V^T P^T) is read from LDS once and feeds both blocks;
+//   * the steady state has NO control flow and no cross-lane work at all.  The score chains start from -m (C operand != D),
+//     where m is a per-row constant taken ONCE per pass from the row's first 32 keys; exp2(s - m) is then summed and
+//     multiplied into V exactly as with a running maximum -- softmax is invariant to the shift, P keeps its relative
+//     precision at any magnitude (16-bit floating point), o and l are fp32.  Only overflow could hurt (a later score
+//     exceeding m by ~2^100 for bf16, ~2^15 for fp16): the row sums are checked ONCE at the end of the pass, and a pass that
+//     fails is redone with the exact row maxima from a max-only sweep (same pipeline, second attempt) -- results are
+//     exact either way, the common case pays nothing per tile;
+//   * one block iteration = one 32-key block for both row blocks = 2 KS score MFMAs + 4 DB  P V MFMAs of the PREVIOUS
+//     key block, with that block's exps / row sums / packs spread evenly under them (D = 64: two exp, two adds and one
+//     pack per MFMA; D = 128: one exp and add per MFMA), each closed by sched_barrier(0);
+//   * the per-tile commit (counted vmcnt, s_barrier) sits inside the tile's last iteration; K/V tiles arrive by LDS-DMA
+//     into a ring of three (D = 64, 128-key tiles) or four (D = 128, 64-key tiles) buffers, one to two tiles ahead.
+// Causal: workgroups take the query-tile pair (nq-1-i, i); the tiles level with the query tile run the same pipeline with a
+// one-compare mask per element (the ragged last tile of a non-causal launch too).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <int D_>
+struct Fwd4Cfg {
+  static constexpr int D = D_;
+  static constexpr int BM = 256, NT = 256, NW = 4;
+  static constexpr int BN = D == 64 ? 128 : 64;             // keys per LDS tile
+  static constexpr int NBUF = D == 64 ? 3 : 4;              // ring depth
+  static constexpr int NKB = BN / 32;                       // 32-key block iterations per tile
+  static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
+  static constexpr int TILE_BYTES = BN * ROWB;              // 16 KiB for both head dims
+  static constexpr int V_BASE = NBUF * TILE_BYTES;          // K[NBUF], then V[NBUF]
+  static constexpr int FLAG_OFF = 2 * NBUF * TILE_BYTES;    // one word: some wave's row sums overflowed
+  static constexpr int LDS_BYTES = FLAG_OFF + 16;
+  static constexpr int PIECES = TILE_BYTES / (NW * 1024);   // 1-KiB LDS-DMA pieces per wave per matrix (4)
+  static constexpr int RPI = 1024 / ROWB;                   // tile rows per piece
+  static constexpr int NSS = 2 * KS, NPV = 4 * DB, NSLOT = NSS + NPV;   // MFMA slots of one block iteration
+  static constexpr int EPS = 32 / NSLOT;                    // exps per slot (2 or 1)
+  static constexpr int INFLIGHT = (NBUF - 3) * 2 * PIECES;  // pieces of later tiles a commit leaves in flight (vmcnt)
+};
+
+// largest row sum accepted at the end of a pass (fa_fwd_v4.hip header): P must stay finite in 16 bit, o and l in fp32
+template <typename T> struct Fwd4Limit;
+template <> struct Fwd4Limit<BF16> { static constexpr float value = 1.2676506e30f; };   // 2^100
+template <> struct Fwd4Limit<FP16> { static constexpr float value = 32768.0f; };        // 2^15 (fp16 max 65504)
+
+template <int D, typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
+  using C = Fwd4Cfg<D>;
+  using vec8 = typename T::vec8;
+  constexpr bool FOLD = T::kFoldScale;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FA_LDS char* smem = (FA_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const bool paired = CAUSAL && p.pair;
+  const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
+  const int bh = w / per_bh;
+  const int idx = w - bh * per_bh;
+  const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
+  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int Sq = p.Sq, Sk = p.Sk;
+
+  // Q, K, V, O may be strided views with a contiguous head dim (fa_fwd.hip); no variable-length launches here
+  const int q_rs = p.lq.rs, kv_rs = p.lk.rs, o_rs = p.lo.rs;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, view_bytes(Sk, kv_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, view_bytes(Sk, kv_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh, view_bytes(Sq, o_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
+
+  // ---- loop-invariant per-lane addresses ----
+  int dma_src[C::PIECES];   // per-lane global source offset of this wave's pieces (K and V share their row stride)
+#pragma unroll
+  for (int i = 0; i < C::PIECES; ++i) {
+    const int row = (C::BN / C::NW) * wave + C::RPI * i + lane / C::CPR;
+    dma_src[i] = row * kv_rs + swz_chunk<D>(row, lane % C::CPR) * 16 - 1024 * (i & 1);   // pieces go out in pairs
+  }
+  int k_off[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) k_off[ks] = lds_off<D>(r, 2 * ks + h);
+  int v_off[2][C::DB];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) v_off[e][db] = tr_lane_off<D>(lane, 8 * e, db);
+  const float c2 = p.scale * kLog2e;
+
+  // the ring is read before it is written in two places (pipeline fill, ragged last tile): keep it finite
+  if (Sk % C::BN != 0) {
+    lds_zero_fill(smem, C::FLAG_OFF, C::NT, tid);
+    __syncthreads();
+  }
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
+    const int q0_wg = qt * C::BM;
+    const int qw = q0_wg + 64 * wave;   // this wave's rows: qw + 32 rb + r, rb = 0, 1
+    if (pass) __syncthreads();          // the previous pass staged its O tile in the ring
+
+    const int kv_end = CAUSAL ? min(Sk, q0_wg + C::BM) : Sk;
+    const int ntiles = (kv_end + C::BN - 1) / C::BN;
+    // tiles [0, nplain) need no mask for ANY row of the workgroup (the tile schedule must be workgroup-uniform)
+    const int nplain = CAUSAL ? min(Sk / C::BN, q0_wg / C::BN) : Sk / C::BN;
+
+    // ---- resident operands: Q^T fragments of both row blocks (B operand), scaled once (bf16) ----
+    u32x4 qf[2][C::KS];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        vec8 q = as_vec8<T>(buf_load16(rq, (qw + 32 * rb + r) * q_rs + (2 * ks + h) * 16));
+        if constexpr (FOLD) q = scale_frag<T>(q, c2);
+        qf[rb][ks] = __builtin_bit_cast(u32x4, q);
+      }
+    // per-lane mask base: score register i of lane (r, h) in a block starting at key kb0 is key kb0 + c_i + 4h, row
+    // qw + 32 rb + r; it is dead iff the key exceeds the row (causal) or the last key:  c_i > thr = base[rb] - kb0
+    int mask_base[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) mask_base[rb] = (CAUSAL ? min(qw + 32 * rb + r, Sk - 1) : Sk - 1) - 4 * h;
+
+    // ---- LDS-DMA of one K/V tile: 2 x PIECES pieces per wave, issued in pairs (one M0 write each) ----
+    auto dma_pair = [&](int t, int j) __attribute__((always_inline)) {   // j: 0 .. PIECES-1; pairs 0 .. PIECES/2-1 K, then V
+      constexpr int HALF = C::PIECES / 2;
+      const int i = 2 * (j % HALF);
+      const int dst = (t % C::NBUF) * C::TILE_BYTES + ((C::BN / C::NW) * wave + C::RPI * i) * C::ROWB;
+      if (j < HALF) dma_pieces<2>(rk, lds_addr_of(smem + dst), dma_src + i, t * C::BN * kv_rs);
+      else dma_pieces<2>(rv, lds_addr_of(smem + C::V_BASE + dst), dma_src + i, t * C::BN * kv_rs);
+    };
+    auto fetch_tile = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < C::PIECES; ++j) dma_pair(t, j);
+    };
+    // tile t + 1 has landed for every wave, and every wave is past its reads of tile t - 1
+    auto commit = [&]() __attribute__((always_inline)) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070 | (C::INFLIGHT & 15) | ((C::INFLIGHT >> 4) << 14));   // vmcnt(INFLIGHT) lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+
+    // ---- pipeline state ----
+    f32x16 S_[2][2];        // [set][row block]: score accumulators -> exponent arguments -> P of a key block
+    f32x16 negm[2];         // [row block]: -m in every register (FOLD: the score chains start from it)
+    float mrow[2], nmc[2];  // the row constant m (accumulator units) and -m * c2 (exact-fma path)
+    float l[2];             // this lane's partial row sums
+    u32x4 pk[2][2][2];      // [set][row block][k-step]: packed P of a key block
+    u32x4 KF[C::KS];        // K row fragments of the key block being scored
+    vec8 VF[2 * C::DB];     // V^T fragments (k-step e, d block db) -> index e * DB + db of the key block being multiplied
+    f32x16 oacc[2][C::DB];
+    int thr[2][2] = {{0, 0}, {0, 0}};   // [set][row block]: mask threshold of a block (masked tiles)
+
+    // VALU work of ONE key block at pipeline time tau (slots since the start of its own iteration): exps q = 0..31 in the
+    // order rb0[0..7], rb1[0..7], rb0[8..15], rb1[8..15], EPS per slot from tau = NSS on; each followed by its row-sum add;
+    // a pair is packed as soon as both its values exist.
+    auto block_valu = [&](int tau, f32x16 (&X)[2], u32x4 (&PK)[2][2], const int (&TH)[2], auto mask_tag) __attribute__((always_inline)) {
+      constexpr bool MASK = decltype(mask_tag)::value;
+#pragma unroll
+      for (int u = 0; u < C::EPS; ++u) {
+        const int q = (tau - C::NSS) * C::EPS + u;
+        if (q < 0 || q >= 32) continue;
+        const int rb = (q >> 3) & 1, e = (q & 7) + 8 * (q >> 4);
+        float x = FOLD ? X[rb][e] : __builtin_fmaf(X[rb][e], c2, nmc[rb]);
+        if constexpr (MASK) x = (e & 3) + 8 * (e >> 2) > TH[rb] ? -INFINITY : x;
+        const float pe = __builtin_amdgcn_exp2f(x);
+        X[rb][e] = pe;
+        l[rb] += pe;
+        if (q & 1) {
+          const int j = e >> 1;   // pair (e - 1, e)
+          PK[rb][j >> 2][j & 3] = pack2<T>(X[rb][e - 1], pe);
+        }
+      }
+    };
+
+    // one block iteration: key block J of the tile in ring slot `rt` (K at kt, V at vt); `kn`: the K image of the NEXT key
+    // block (next tile after the last block), `vp`: the V image of the PREVIOUS key block.  hook(J, s) runs before slot s.
+    // LDS addresses are `per-lane base register (set once per tile, opaque to hipcc) + immediate`: left alone, hipcc hoists
+    // every (lane offset + constant) pair out of the tile loop -- thirty values parked in AGPRs and ~100 vector instructions
+    // per tile to rebuild the addresses from them (the ring is larger than the 16-bit immediate of ds_read)
+    auto block_iter = [&](auto j_tag, auto set_tag, auto mask_tag, int kb0, const int (&kn)[C::KS], int kn_imm,
+                          const int (&vc)[2][C::DB], int vc_imm, int vp0, int vp1, int vp_imm,
+                          auto&& hook) __attribute__((always_inline)) {
+      constexpr int J = decltype(j_tag)::value, SET = decltype(set_tag)::value, PSET = SET ^ 1;
+      if constexpr (decltype(mask_tag)::value) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) thr[SET][rb] = mask_base[rb] - kb0;
+      }
+#pragma unroll
+      for (int s = 0; s < C::NSLOT; ++s) {
+        hook(J, s);
+        // ---- the MFMA of this slot ----
+        if (s < C::NSS) {
+          const int ks = s >> 1, rb = s & 1;
+          if (ks == 0) {
+            if constexpr (FOLD) T::mfma_v_first(S_[SET][rb], KF[0], qf[rb][0], negm[rb]);
+            else T::mfma_v_first0(S_[SET][rb], KF[0], qf[rb][0]);
+          } else {
+            T::mfma_v_acc(S_[SET][rb], KF[ks], qf[rb][ks]);
+          }
+        } else {   // P V of the previous key block: (k-step e, d block db) = (pp / DB, pp % DB), row block n & 1
+          const int n = s - C::NSS, rb = n & 1, pp = n >> 1, e = pp / C::DB, db = pp % C::DB;
+          oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
+        }
+        // ---- LDS reads into registers whose last use is just over ----
+        if (s >= 2 && s <= C::NSS && (s & 1) == 0) {   // K fragment of the NEXT key block (used from slot 2 ks of the next iteration)
+          const int ks = (s - 2) >> 1;
+          KF[ks] = lds_read16(smem + kn[ks] + kn_imm);
+        }
+        if (s >= C::NSS + 2 && ((s - C::NSS) & 1) == 0) {   // V^T fragment of THIS key block (multiplied in the next iteration)
+          const int pp = (s - C::NSS - 2) >> 1, e = pp / C::DB, db = pp % C::DB;
+          VF[pp] = lds_read_tr_frag<T>(smem + vc[0][db] + vc_imm + 16 * e * C::ROWB, smem + vc[1][db] + vc_imm + 16 * e * C::ROWB);
+        }
+        if (s == 0) {   // the last V^T fragment (k-step 1, last d block) of the PREVIOUS key block: its register was busy until the last slot
+          constexpr int pp = 2 * C::DB - 1;
+          VF[pp] = lds_read_tr_frag<T>(smem + vp0 + vp_imm, smem + vp1 + vp_imm);
+        }
+        // ---- VALU: the previous key block at tau = NSLOT + s, this one at tau = s ----
+        block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], mask_tag);
+        block_valu(s, S_[SET], pk[SET], thr[SET], mask_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // the last key block's remaining softmax and its P V once nothing follows it
+    auto drain = [&](auto set_tag, auto mask_tag, int t_last) __attribute__((always_inline)) {
+      constexpr int PSET = decltype(set_tag)::value ^ 1;
+      {   // the last V^T fragment of the last key block (read at slot 0 of the following iteration in the steady state)
+        const int base = C::V_BASE + (t_last % C::NBUF) * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB + 16 * C::ROWB;
+        VF[2 * C::DB - 1] = lds_read_tr_frag<T>(smem + v_off[0][C::DB - 1] + base, smem + v_off[1][C::DB - 1] + base);
+      }
+#pragma unroll
+      for (int s = 0; s < C::NSLOT; ++s) {
+        if (s >= C::NSS) {
+          const int n = s - C::NSS, rb = n & 1, pp = n >> 1, e = pp / C::DB, db = pp % C::DB;
+          oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
+        }
+        block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], mask_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // one tile: NKB block iterations; the commit + the DMA of tile t + NBUF - 1 ride in the last one
+    auto tile_step = [&](int t, auto mask_tag) __attribute__((always_inline)) {
+      const int rt = t % C::NBUF, rn = (t + 1) % C::NBUF, rp = (t + C::NBUF - 1) % C::NBUF;
+      // per-lane bases of this tile's K and V images, of the next tile's K image and of the previous tile's last V fragment
+      // (the very first iteration has no previous key block -- its P is 0 -- but must read a FINITE image: ring slot
+      // NBUF - 1 has not been written yet and uninitialised LDS may hold NaN patterns, so it reads this tile's own)
+      int kA[C::KS], kN[C::KS], vA[2][C::DB], vP[2];
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        kA[ks] = opaque(k_off[ks] + rt * C::TILE_BYTES);
+        kN[ks] = opaque(k_off[ks] + rn * C::TILE_BYTES);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) vA[e][db] = opaque(v_off[e][db] + C::V_BASE + rt * C::TILE_BYTES);
+        vP[e] = opaque(v_off[e][C::DB - 1] + C::V_BASE + (t == 0 ? rt * C::TILE_BYTES
+                                                                  : rp * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB) + 16 * C::ROWB);
+      }
+      auto hook = [&](int J, int s) __attribute__((always_inline)) {
+        if (J == C::NKB - 1) {
+          if (s == 1) commit();   // before the first read of tile t + 1 (slot 2), after every read of tile t - 1
+#pragma unroll
+          for (int j = 0; j < C::PIECES; ++j)
+            if (s == C::NSS + 1 + 2 * j) dma_pair(t + C::NBUF - 1, j);   // into the buffer tile t - 1 has just left
+        }
+      };
+      auto go = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value;
+        constexpr int kPrevImm = (J - 1) * 32 * C::ROWB + 16 * C::ROWB;   // J > 0: the previous key block lies in this tile
+        if constexpr (J == 0)
+          block_iter(j_tag, std::integral_constant<int, 0>{}, mask_tag, t * C::BN, kA, 32 * C::ROWB, vA, 0, vP[0], vP[1], 0, hook);
+        else if constexpr (J + 1 < C::NKB)
+          block_iter(j_tag, std::integral_constant<int, J & 1>{}, mask_tag, t * C::BN + 32 * J, kA, (J + 1) * 32 * C::ROWB, vA,
+                     J * 32 * C::ROWB, vA[0][C::DB - 1], vA[1][C::DB - 1], kPrevImm, hook);
+        else
+          block_iter(j_tag, std::integral_constant<int, J & 1>{}, mask_tag, t * C::BN + 32 * J, kN, 0, vA, J * 32 * C::ROWB,
+                     vA[0][C::DB - 1], vA[1][C::DB - 1], kPrevImm, hook);
+      };
+      go(std::integral_constant<int, 0>{});
+      go(std::integral_constant<int, 1>{});
+      if constexpr (C::NKB == 4) {
+        go(std::integral_constant<int, 2>{});
+        go(std::integral_constant<int, 3>{});
+      }
+    };
+
+    // ---- the row constant m: first attempt from the row's first 32 keys, second attempt (only after an overflow) exact ----
+    // scores of key block `kb0` of the tile at `kt` for both row blocks (masked), folded into a running maximum
+    auto scout_block = [&](const FA_LDS char* kblk, int kb0, float (&mx)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x16 s;
+        T::mfma_v_first0(s, lds_read16(kblk + k_off[0]), qf[rb][0]);
+#pragma unroll
+        for (int ks = 1; ks < C::KS; ++ks) T::mfma_v_acc(s, lds_read16(kblk + k_off[ks]), qf[rb][ks]);
+        settle_mfma(s);   // asm MFMA result -> VALU reader (hipcc pads nothing around asm)
+        const int th = mask_base[rb] - kb0;
+        float mm = mx[rb];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mm = __builtin_fmaxf(mm, (i & 3) + 8 * (i >> 2) > th ? -INFINITY : s[i]);
+        mx[rb] = mm;
+      }
+    };
+    auto set_m = [&](const float (&mx)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        // a row that sees no key at all (rows past S_q) keeps a finite constant: its P is 0 everywhere, O is never stored
+        const float m = half_max(mx[rb]);
+        mrow[rb] = m > -INFINITY ? m : 0.f;
+        nmc[rb] = -mrow[rb] * c2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[rb][i] = -mrow[rb];
+      }
+    };
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      // ---- prologue: the first NBUF - 1 tiles on their way, tile 0 landed ----
+#pragma unroll
+      for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+      asm volatile("" ::: "memory");
+      // tile 0 = the oldest 2 * PIECES pieces: leave the later tiles' pieces in flight
+      __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+
+      float mx[2] = {-INFINITY, -INFINITY};
+      if (attempt == 0) {
+        scout_block(smem, 0, mx);                 // keys 0..31: key 0 is visible to every row (top-left aligned mask)
+        set_m(mx);
+      } else {
+        // exact row maxima: a max-only sweep over every tile (cold path: reached only after an overflow)
+        for (int t = 0; t < ntiles; ++t) {
+          if (t > 0) {
+            __syncthreads();
+            fetch_tile(t);
+            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+            __syncthreads();
+          }
+          for (int j = 0; j < C::NKB; ++j)
+            scout_block(smem + (t % C::NBUF) * C::TILE_BYTES + j * 32 * C::ROWB, t * C::BN + 32 * j, mx);
+        }
+        set_m(mx);
+        // restart the ring
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+
+      // ---- pipeline fill: a neutral "previous key block" (P = 0), the first K fragments ----
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        l[rb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S_[1][rb][i] = i < 8 ? 0.f : -INFINITY;   // elements 0-7 "done" (P = 0), 8-15 give exp2(-inf)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pk[1][rb][e] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[rb][db][i] = 0.f;
+        thr[1][rb] = 1 << 20;   // nothing of the neutral block is masked (its arguments are -inf already)
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) KF[ks] = lds_read16(smem + k_off[ks]);
+#pragma unroll
+      for (int pp = 0; pp < 2 * C::DB; ++pp) VF[pp] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
+      __builtin_amdgcn_sched_barrier(0);
+
+      int t = 0;
+      for (; t < nplain; ++t) tile_step(t, std::false_type{});
+      for (; t < ntiles; ++t) tile_step(t, std::true_type{});
+      // the set of the last block: NKB is even, so it is always set 1 -> the drain's "previous" set is 1
+      drain(std::integral_constant<int, 0>{}, std::true_type{}, ntiles - 1);
+
+      // ---- end-of-pass check: every row sum finite and below the limit, for the whole workgroup ----
+      float lt[2];
+      bool bad = false;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        lt[rb] = half_sum(l[rb]);
+        bad = bad || !(lt[rb] <= Fwd4Limit<T>::value);
+      }
+      FA_LDS int* flag = (FA_LDS int*)(smem + C::FLAG_OFF);
+      __builtin_amdgcn_s_waitcnt(0x0070);   // every DMA of the pass retired (the ring is reused below)
+      __syncthreads();
+      if (tid == 0) *flag = 0;
+      __syncthreads();
+      if (attempt == 0 && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *flag = 1;
+      __syncthreads();
+      const int redo = __builtin_amdgcn_readfirstlane(*flag);
+      if (!redo) {
+        // ---- epilogue: O = o / l (rows of the ring are free: every wave is past the barrier above) ----
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const float inv = lt[rb] > 0.f ? 1.0f / lt[rb] : 0.f;
+          store_tile_rows<D, T>(oacc[rb], inv, smem + (wave * 2 + rb) * 32 * C::ROWB, ro, (qw + 32 * rb) * o_rs, lane, o_rs);
+          if (h == 0)
+            buf_store_f32(rl, (qw + 32 * rb + r) * 4, mrow[rb] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt[rb]));
+        }
+        break;
+      }
+      __syncthreads();
+    }  // attempt
+  }  // pass
+}
+
+template <int D, typename T, bool CAUSAL>
+static hipError_t launch4(const FwdParams& p, hipStream_t s) {
+  using C = Fwd4Cfg<D>;
+  const int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
+  auto kern = fa_fwd4_kernel<D, T, CAUSAL>;
+  static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
+  if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES, opted_in)) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fwd_v4(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
+  p.nq_tiles = (p.Sq + 255) / 256;
+  p.pair = causal != 0;
+#define FA_GO(DD, TT) (causal ? launch4<DD, TT, true>(p, s) : launch4<DD, TT, false>(p, s))
+  if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
+  if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);
+#undef FA_GO
+  return hipErrorInvalidValue;
+}
+
+}  // namespace fa

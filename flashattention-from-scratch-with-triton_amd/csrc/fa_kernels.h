@@ -139,6 +139,8 @@ inline hipError_t opt_in_lds(const void* kern, int bytes, std::atomic<unsigned l
 //   forward   1 = fa_fwd.hip      128-row workgroups, 32 rows per wave, up to 3 waves per SIMD  (D = 64, 128)
 //             2 = fa_fwd_v2.hip   256-row workgroups, 64 rows per wave sharing every K/V fragment (D = 64, fixed length)
 //             3 = fa_fwd_v3.hip   128-row workgroups, per-wave three-stage software pipeline (D = 64)
+//             4 = fa_fwd_v4.hip   256-row workgroups, ONE wave per SIMD with 64 rows, continuous hand-ordered pipeline,
+//                                 row constant m fixed per pass and verified at its end (D = 64, 128; fixed length)
 //   dQ        1 = fa_bwd_dq.hip   as forward 1;  2 = fa_bwd_dq_v2.hip as forward 2;
 //             3 = fa_bwd_dq_v3.hip  128-row workgroups, per-wave three-stage software pipeline (D = 64)
 //   dK/dV     1 = fa_bwd_dkv.hip  128-key workgroups, 64-row Q/dO tiles;
@@ -168,7 +170,8 @@ inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int
   int f = forced ? forced : table_family(kKernelFwd, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
   if (f == 2 && (D != 64 || !fixed_length)) f = 1;
   if (f == 3 && D != 64) f = 1;
-  return (f == 2 || f == 3) ? f : 1;
+  if (f == 4 && !fixed_length) f = 1;
+  return (f >= 2 && f <= 4) ? f : 1;
 }
 inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
   int f = forced ? forced : table_family(kKernelDq, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);

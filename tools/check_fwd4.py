@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Forward family F against family 1 and an fp32 reference on the GPU: O and LSE errors over a list of shapes (incl. ragged,
+cross-attention, S_q != S_k causal, a late score spike that overflows the fixed row constant).  usage: check_fwd4.py [F]"""
+import ctypes, math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flashattention-from-scratch-with-triton_amd"))
+import torch
+import _mi355fa as host
+lib = host.lib
+lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+SHAPES = [(1, 2, 64, 64), (1, 2, 128, 128), (2, 3, 192, 192), (1, 2, 256, 256), (2, 2, 320, 320), (1, 2, 448, 448),
+          (1, 1, 512, 512), (2, 2, 1024, 1024), (1, 2, 500, 500), (1, 2, 77, 333), (1, 2, 333, 77), (1, 1, 129, 65),
+          (1, 2, 128, 320), (1, 2, 256, 1024), (1, 1, 1, 700), (2, 4, 2048, 2048), (1, 2, 4096, 4096)]
+P = lambda t: t.data_ptr()
+bad = 0
+def ref(Q, K, V, causal, sc):
+    S = (Q.float() @ K.float().transpose(-1, -2)) * sc
+    if causal:
+        Sq, Sk = S.shape[-2:]
+        S = S.masked_fill(torch.arange(Sk, device=S.device)[None, :] > torch.arange(Sq, device=S.device)[:, None], float("-inf"))
+    lse = torch.logsumexp(S, dim=-1)
+    return torch.softmax(S, dim=-1) @ V.float(), lse
+for D in (64, 128):
+    for dt, code in ((torch.bfloat16, 1), (torch.float16, 0)):
+        for causal in (0, 1):
+            for shp in SHAPES + ["spike"]:
+                spike = shp == "spike"
+                B, H, Sq, Sk = (1, 2, 512, 512) if spike else shp
+                torch.manual_seed(Sq * 7 + Sk)
+                Q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+                K, V = (torch.randn(B, H, Sk, D, device="cuda", dtype=dt) for _ in range(2))
+                if spike:   # key 300 scores far above everything before it (a jump > 2^15 for fp16 / > 2^100 for bf16 rows)
+                    K[:, :, 300, :] = (Q[:, :, 400, :].float() * (3.0 if dt == torch.float16 else 40.0)).to(dt)
+                st = torch.cuda.current_stream().cuda_stream
+                sc = D ** -0.5
+                outs = []
+                for fam in (1, F):
+                    lib.fa_debug_force_impl(fam, 0, 0)
+                    o, lse = torch.full_like(Q, float("nan")), torch.full((B, H, Sq), float("nan"), device="cuda")
+                    rc = lib.fa_fwd(P(Q), P(K), P(V), P(o), P(lse), B, H, Sq, Sk, D, code, causal, sc, st)
+                    assert rc == 0, lib.fa_last_error()
+                    outs.append((o.float(), lse))
+                torch.cuda.synchronize()
+                lib.fa_debug_force_impl(0, 0, 0)
+                ro, rl = ref(Q, K, V, causal, sc)
+                rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+                e1, e4 = rel(outs[0][0], ro), rel(outs[1][0], ro)
+                l1, l4 = (outs[0][1] - rl).abs().max().item(), (outs[1][1] - rl).abs().max().item()
+                nan = torch.isnan(outs[1][0]).any().item() or torch.isnan(outs[1][1]).any().item()
+                ok = (not nan) and e4 < max(1.5 * e1, 1e-4) + 1e-4 and l4 < max(2 * l1, 1e-3) + 1e-3
+                if not ok:
+                    bad += 1
+                print("%s D%d %s causal=%d B%d H%d Sq%d Sk%d%s  O relFro fam1 %.2e fam%d %.2e   |dLSE| fam1 %.1e fam%d %.1e%s" % (
+                    "ok  " if ok else "FAIL", D, str(dt)[6:], causal, B, H, Sq, Sk, " SPIKE" if spike else "", e1, F, e4, l1, F, l4,
+                    " NaN" if nan else ""), flush=True)
+print("check_fwd family %d: %s" % (F, "ALL OK" if not bad else "%d failures" % bad))
+sys.exit(1 if bad else 0)
