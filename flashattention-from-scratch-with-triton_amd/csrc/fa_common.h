@@ -320,6 +320,7 @@ FA_DEVINL void dma_pieces(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, const 
   }
 }
 FA_DEVINL unsigned lds_addr_of(const FA_LDS char* p) { return (unsigned)(uintptr_t)p; }
+FA_DEVINL const FA_LDS char* lds_at(int addr) { return (const FA_LDS char*)(uintptr_t)(unsigned)addr; }   // absolute LDS byte address -> pointer
 
 // ---- cross-half exchange (lanes l <-> l + 32) -----------------------------
 // v_permlane32_swap_b32 vdst, src swaps lanes 32..63 of vdst with lanes 0..31 of src.  Fed two

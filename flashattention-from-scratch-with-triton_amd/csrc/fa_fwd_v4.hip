@@ -24,8 +24,11 @@
 //     pack per MFMA; D = 128: one exp and add per MFMA), each closed by sched_barrier(0);
 //   * the per-tile commit (counted vmcnt, s_barrier) sits inside the tile's last iteration; K/V tiles arrive by LDS-DMA
 //     into a ring of three (D = 64, 128-key tiles) or four (D = 128, 64-key tiles) buffers, one to two tiles ahead.
-// Causal: workgroups take the query-tile pair (nq-1-i, i); the tiles level with the query tile run the same pipeline with a
-// one-compare mask per element (the ragged last tile of a non-causal launch too).
+// Causal: workgroups take the query-tile pair (nq-1-i, i).  A wave's two row blocks lie in the two HALVES of the 256-row
+// tile (rows 32w.. and 128 + 32w..): of the 256 keys level with the query tile the first 128 are unmasked for every row
+// block 1 and the second 128 invisible to every row block 0 -- those tiles run the same pipeline with a one-compare mask per
+// element on one row block only, respectively without row block 0 at all (half the MFMAs); the ragged last tile of any
+// launch masks both row blocks.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -64,6 +67,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
   using C = Fwd4Cfg<D>;
   using vec8 = typename T::vec8;
   constexpr bool FOLD = T::kFoldScale;
+  // the score chains start from -m (a 16-register block per row block) where vector issue is the bound (D = 64); at
+  // D = 128 the matrix pipe is, registers are short, and one subtraction per element is free: chains start from 0
+#ifdef FA_FWD4_CHAIN_ALL   // A/B hook
+  constexpr bool CHAIN_M = FOLD;
+#else
+  constexpr bool CHAIN_M = FOLD && D == 64;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
@@ -112,45 +122,58 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
     __syncthreads();
   }
 
+  if (tid == 0) *(FA_LDS int*)(smem + C::FLAG_OFF) = 0;   // "some wave's row sums overflowed" (ordered by the first barrier below)
+  bool primed = false;   // the first NBUF - 1 tiles of the ring are on their way (issued before the previous pass's epilogue)
+
   for (int pass = 0; pass < npass; ++pass) {
     const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
     const int q0_wg = qt * C::BM;
-    const int qw = q0_wg + 64 * wave;   // this wave's rows: qw + 32 rb + r, rb = 0, 1
-    if (pass) __syncthreads();          // the previous pass staged its O tile in the ring
+    // this wave's two 32-row blocks: rows qrow(rb) + r with qrow(rb) = q0_wg + 128 rb + 32 wave -- one block in each half
+    // of the 256-row tile, so that under the causal mask the SECOND half of the key tiles level with the query tile is
+    // invisible to row block 0 of EVERY wave (skipped outright) and the first half is unmasked for every row block 1
+    const int qw = q0_wg + 32 * wave;
+    auto qrow = [&](int rb) __attribute__((always_inline)) { return qw + 128 * rb; };
 
     const int kv_end = CAUSAL ? min(Sk, q0_wg + C::BM) : Sk;
     const int ntiles = (kv_end + C::BN - 1) / C::BN;
     // tiles [0, nplain) need no mask for ANY row of the workgroup (the tile schedule must be workgroup-uniform)
     const int nplain = CAUSAL ? min(Sk / C::BN, q0_wg / C::BN) : Sk / C::BN;
 
+    // ---- LDS-DMA of one K/V tile: 2 x PIECES pieces per wave, issued in pairs (one M0 write each) ----
+    auto dma_pair = [&](int t, int slot, int j) __attribute__((always_inline)) {   // j: 0 .. PIECES-1; pairs 0 .. PIECES/2-1 K, then V
+      constexpr int HALF = C::PIECES / 2;
+      const int i = 2 * (j % HALF);
+      const int dst = slot * C::TILE_BYTES + ((C::BN / C::NW) * wave + C::RPI * i) * C::ROWB;
+      if (j < HALF) dma_pieces<2>(rk, lds_addr_of(smem + dst), dma_src + i, t * C::BN * kv_rs);
+      else dma_pieces<2>(rv, lds_addr_of(smem + C::V_BASE + dst), dma_src + i, t * C::BN * kv_rs);
+    };
+    auto fetch_tile = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < C::PIECES; ++j) dma_pair(t, t % C::NBUF, j);
+    };
+    // The K/V tiles do not depend on the query tile: the ring is primed BEFORE the Q fragments are fetched (one memory
+    // latency per pass instead of two), for a second pass already before the first pass's epilogue.
+    if (!primed) {
+#pragma unroll
+      for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+      primed = true;
+    }
     // ---- resident operands: Q^T fragments of both row blocks (B operand), scaled once (bf16) ----
     u32x4 qf[2][C::KS];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        vec8 q = as_vec8<T>(buf_load16(rq, (qw + 32 * rb + r) * q_rs + (2 * ks + h) * 16));
+        vec8 q = as_vec8<T>(buf_load16(rq, (qrow(rb) + r) * q_rs + (2 * ks + h) * 16));
         if constexpr (FOLD) q = scale_frag<T>(q, c2);
         qf[rb][ks] = __builtin_bit_cast(u32x4, q);
       }
     // per-lane mask base: score register i of lane (r, h) in a block starting at key kb0 is key kb0 + c_i + 4h, row
-    // qw + 32 rb + r; it is dead iff the key exceeds the row (causal) or the last key:  c_i > thr = base[rb] - kb0
+    // qrow(rb) + r; it is dead iff the key exceeds the row (causal) or the last key:  c_i > thr = base[rb] - kb0
     int mask_base[2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) mask_base[rb] = (CAUSAL ? min(qw + 32 * rb + r, Sk - 1) : Sk - 1) - 4 * h;
+    for (int rb = 0; rb < 2; ++rb) mask_base[rb] = (CAUSAL ? min(qrow(rb) + r, Sk - 1) : Sk - 1) - 4 * h;
 
-    // ---- LDS-DMA of one K/V tile: 2 x PIECES pieces per wave, issued in pairs (one M0 write each) ----
-    auto dma_pair = [&](int t, int j) __attribute__((always_inline)) {   // j: 0 .. PIECES-1; pairs 0 .. PIECES/2-1 K, then V
-      constexpr int HALF = C::PIECES / 2;
-      const int i = 2 * (j % HALF);
-      const int dst = (t % C::NBUF) * C::TILE_BYTES + ((C::BN / C::NW) * wave + C::RPI * i) * C::ROWB;
-      if (j < HALF) dma_pieces<2>(rk, lds_addr_of(smem + dst), dma_src + i, t * C::BN * kv_rs);
-      else dma_pieces<2>(rv, lds_addr_of(smem + C::V_BASE + dst), dma_src + i, t * C::BN * kv_rs);
-    };
-    auto fetch_tile = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-      for (int j = 0; j < C::PIECES; ++j) dma_pair(t, j);
-    };
     // tile t + 1 has landed for every wave, and every wave is past its reads of tile t - 1
     auto commit = [&]() __attribute__((always_inline)) {
       asm volatile("" ::: "memory");
@@ -161,49 +184,67 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
 
     // ---- pipeline state ----
     f32x16 S_[2][2];        // [set][row block]: score accumulators -> exponent arguments -> P of a key block
-    f32x16 negm[2];         // [row block]: -m in every register (FOLD: the score chains start from it)
+    f32x16 negm[CHAIN_M ? 2 : 1];   // [row block]: -m in every register (CHAIN_M: the score chains start from it)
     float mrow[2], nmc[2];  // the row constant m (accumulator units) and -m * c2 (exact-fma path)
     float l[2];             // this lane's partial row sums
     u32x4 pk[2][2][2];      // [set][row block][k-step]: packed P of a key block
-    u32x4 KF[C::KS];        // K row fragments of the key block being scored
+#ifdef FA_FWD4_KR_FULL   // A/B hook
+    constexpr int KR = C::KS;
+#else
+    constexpr int KR = C::KS < 4 ? C::KS : 4;   // K fragment ring: fragment ks lives in KF[ks % KR]
+#endif
+    u32x4 KF[KR];           // K row fragments of the key block being scored
     vec8 VF[2 * C::DB];     // V^T fragments (k-step e, d block db) -> index e * DB + db of the key block being multiplied
     f32x16 oacc[2][C::DB];
-    int thr[2][2] = {{0, 0}, {0, 0}};   // [set][row block]: mask threshold of a block (masked tiles)
+    int thr[2][2];   // [set][row block]: mask threshold of a block; plain blocks leave the neutral 1 << 20 of the fill (masks nothing)
 
     // VALU work of ONE key block at pipeline time tau (slots since the start of its own iteration): exps q = 0..31 in the
-    // order rb0[0..7], rb1[0..7], rb0[8..15], rb1[8..15], EPS per slot from tau = NSS on; each followed by its row-sum add;
-    // a pair is packed as soon as both its values exist.
-    auto block_valu = [&](int tau, f32x16 (&X)[2], u32x4 (&PK)[2][2], const int (&TH)[2], auto mask_tag) __attribute__((always_inline)) {
-      constexpr bool MASK = decltype(mask_tag)::value;
+    // order rb0[0..7], rb1[0..7], rb0[8..15], rb1[8..15], EPS per slot from tau = NSS on; the row-sum add of a value and
+    // the pack of a pair follow ONE SLOT later (the last ones at tau = NSLOT + NSS, before the first P V MFMA that needs them).
+    auto block_valu = [&](int tau, f32x16 (&X)[2], u32x4 (&PK)[2][2], const int (&TH)[2], auto mask_tag, auto has0_tag) __attribute__((always_inline)) {
+      constexpr bool MASK = decltype(mask_tag)::value, HAS0 = decltype(has0_tag)::value;   // HAS0: row block 0 takes part
 #pragma unroll
       for (int u = 0; u < C::EPS; ++u) {
         const int q = (tau - C::NSS) * C::EPS + u;
         if (q < 0 || q >= 32) continue;
         const int rb = (q >> 3) & 1, e = (q & 7) + 8 * (q >> 4);
-        float x = FOLD ? X[rb][e] : __builtin_fmaf(X[rb][e], c2, nmc[rb]);
+        if (rb == 0 && !HAS0) continue;
+        float x = CHAIN_M ? X[rb][e] : (FOLD ? X[rb][e] + nmc[rb] : __builtin_fmaf(X[rb][e], c2, nmc[rb]));
         if constexpr (MASK) x = (e & 3) + 8 * (e >> 2) > TH[rb] ? -INFINITY : x;
-        const float pe = __builtin_amdgcn_exp2f(x);
-        X[rb][e] = pe;
-        l[rb] += pe;
+        X[rb][e] = __builtin_amdgcn_exp2f(x);
+      }
+      // row sums and packs of the PREVIOUS slot's exps: a transcendental's result is not there for the next instruction
+#pragma unroll
+      for (int u = 0; u < C::EPS; ++u) {
+        const int q = (tau - 1 - C::NSS) * C::EPS + u;
+        if (q < 0 || q >= 32) continue;
+        const int rb = (q >> 3) & 1, e = (q & 7) + 8 * (q >> 4);
+        if (rb == 0 && !HAS0) continue;
+        l[rb] += X[rb][e];
         if (q & 1) {
           const int j = e >> 1;   // pair (e - 1, e)
-          PK[rb][j >> 2][j & 3] = pack2<T>(X[rb][e - 1], pe);
+          PK[rb][j >> 2][j & 3] = pack2<T>(X[rb][e - 1], X[rb][e]);
         }
       }
     };
-
-    // one block iteration: key block J of the tile in ring slot `rt` (K at kt, V at vt); `kn`: the K image of the NEXT key
-    // block (next tile after the last block), `vp`: the V image of the PREVIOUS key block.  hook(J, s) runs before slot s.
     // LDS addresses are `per-lane base register (set once per tile, opaque to hipcc) + immediate`: left alone, hipcc hoists
     // every (lane offset + constant) pair out of the tile loop -- thirty values parked in AGPRs and ~100 vector instructions
     // per tile to rebuild the addresses from them (the ring is larger than the 16-bit immediate of ds_read)
-    auto block_iter = [&](auto j_tag, auto set_tag, auto mask_tag, int kb0, const int (&kn)[C::KS], int kn_imm,
+    // MODE of the block in flight: 0 plain, 1 both row blocks masked element-wise, 2 row block 0 masked / row block 1 plain,
+    // 3 row block 0 absent (invisible to every wave) / row block 1 masked.  PST = what the PREVIOUS block was: 0 plain, 1 masked
+    // (some row block, element-wise; a plain row block of it carries a threshold that masks nothing), 2 masked without row block 0.
+    auto block_iter = [&](auto j_tag, auto set_tag, auto mode_tag, auto pst_tag, int kb0, const int (&kc)[C::KS], int kc_imm,
+                          const int (&kn)[C::KS], int kn_delta, int kn_imm,
                           const int (&vc)[2][C::DB], int vc_imm, int vp0, int vp1, int vp_imm,
                           auto&& hook) __attribute__((always_inline)) {
       constexpr int J = decltype(j_tag)::value, SET = decltype(set_tag)::value, PSET = SET ^ 1;
-      if constexpr (decltype(mask_tag)::value) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) thr[SET][rb] = mask_base[rb] - kb0;
+      constexpr int MODE = decltype(mode_tag)::value, PST = decltype(pst_tag)::value;
+      constexpr bool OWN0 = MODE != 3, PREV0 = PST != 2;
+      using OwnMask = std::integral_constant<bool, MODE != 0>;
+      using PrevMask = std::integral_constant<bool, PST != 0>;
+      if constexpr (MODE != 0) {
+        thr[SET][0] = mask_base[0] - kb0;
+        thr[SET][1] = MODE == 2 ? (1 << 20) : mask_base[1] - kb0;
       }
 #pragma unroll
       for (int s = 0; s < C::NSLOT; ++s) {
@@ -211,38 +252,44 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         // ---- the MFMA of this slot ----
         if (s < C::NSS) {
           const int ks = s >> 1, rb = s & 1;
-          if (ks == 0) {
-            if constexpr (FOLD) T::mfma_v_first(S_[SET][rb], KF[0], qf[rb][0], negm[rb]);
-            else T::mfma_v_first0(S_[SET][rb], KF[0], qf[rb][0]);
-          } else {
-            T::mfma_v_acc(S_[SET][rb], KF[ks], qf[rb][ks]);
+          if (rb == 1 || OWN0) {
+            if (ks == 0) {
+              if constexpr (CHAIN_M) T::mfma_v_first(S_[SET][rb], KF[0], qf[rb][0], negm[CHAIN_M ? rb : 0]);
+              else T::mfma_v_first0(S_[SET][rb], KF[0], qf[rb][0]);
+            } else {
+              T::mfma_v_acc(S_[SET][rb], KF[ks % KR], qf[rb][ks]);
+            }
           }
         } else {   // P V of the previous key block: (k-step e, d block db) = (pp / DB, pp % DB), row block n & 1
           const int n = s - C::NSS, rb = n & 1, pp = n >> 1, e = pp / C::DB, db = pp % C::DB;
-          oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
+          if (rb == 1 || PREV0) oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
         }
         // ---- LDS reads into registers whose last use is just over ----
-        if (s >= 2 && s <= C::NSS && (s & 1) == 0) {   // K fragment of the NEXT key block (used from slot 2 ks of the next iteration)
-          const int ks = (s - 2) >> 1;
-          KF[ks] = lds_read16(smem + kn[ks] + kn_imm);
+        if (s >= 2 && s <= C::NSS && (s & 1) == 0) {
+          // the ring register of fragment ks = (s - 2) / 2 is free (its MFMAs were slots s - 2, s - 1): it takes fragment
+          // ks + KR of THIS key block while one is left, else fragment ks + KR - KS of the NEXT key block
+          const int ks = (s - 2) >> 1, nk = ks + KR;
+          if (nk < C::KS) KF[ks % KR] = lds_read16(lds_at(kc[nk] + kc_imm));
+          else KF[ks % KR] = lds_read16(lds_at(kn[nk - C::KS] + kn_delta + kn_imm));
         }
         if (s >= C::NSS + 2 && ((s - C::NSS) & 1) == 0) {   // V^T fragment of THIS key block (multiplied in the next iteration)
           const int pp = (s - C::NSS - 2) >> 1, e = pp / C::DB, db = pp % C::DB;
-          VF[pp] = lds_read_tr_frag<T>(smem + vc[0][db] + vc_imm + 16 * e * C::ROWB, smem + vc[1][db] + vc_imm + 16 * e * C::ROWB);
+          VF[pp] = lds_read_tr_frag<T>(lds_at(vc[0][db] + vc_imm + 16 * e * C::ROWB), lds_at(vc[1][db] + vc_imm + 16 * e * C::ROWB));
         }
         if (s == 0) {   // the last V^T fragment (k-step 1, last d block) of the PREVIOUS key block: its register was busy until the last slot
           constexpr int pp = 2 * C::DB - 1;
-          VF[pp] = lds_read_tr_frag<T>(smem + vp0 + vp_imm, smem + vp1 + vp_imm);
+          VF[pp] = lds_read_tr_frag<T>(lds_at(vp0 + vp_imm), lds_at(vp1 + vp_imm));
         }
         // ---- VALU: the previous key block at tau = NSLOT + s, this one at tau = s ----
-        block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], mask_tag);
-        block_valu(s, S_[SET], pk[SET], thr[SET], mask_tag);
+        block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], PrevMask{}, std::integral_constant<bool, PREV0>{});
+        block_valu(s, S_[SET], pk[SET], thr[SET], OwnMask{}, std::integral_constant<bool, OWN0>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     // the last key block's remaining softmax and its P V once nothing follows it
-    auto drain = [&](auto set_tag, auto mask_tag, int t_last) __attribute__((always_inline)) {
-      constexpr int PSET = decltype(set_tag)::value ^ 1;
+    auto drain = [&](auto set_tag, auto pst_tag, int t_last) __attribute__((always_inline)) {
+      constexpr int PSET = decltype(set_tag)::value ^ 1, PST = decltype(pst_tag)::value;
+      constexpr bool PREV0 = PST != 2;
       {   // the last V^T fragment of the last key block (read at slot 0 of the following iteration in the steady state)
         const int base = C::V_BASE + (t_last % C::NBUF) * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB + 16 * C::ROWB;
         VF[2 * C::DB - 1] = lds_read_tr_frag<T>(smem + v_off[0][C::DB - 1] + base, smem + v_off[1][C::DB - 1] + base);
@@ -251,30 +298,33 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       for (int s = 0; s < C::NSLOT; ++s) {
         if (s >= C::NSS) {
           const int n = s - C::NSS, rb = n & 1, pp = n >> 1, e = pp / C::DB, db = pp % C::DB;
-          oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
+          if (rb == 1 || PREV0) oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
         }
-        block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], mask_tag);
+        block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], std::integral_constant<bool, PST != 0>{}, std::integral_constant<bool, PREV0>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 
     // one tile: NKB block iterations; the commit + the DMA of tile t + NBUF - 1 ride in the last one
-    auto tile_step = [&](int t, auto mask_tag) __attribute__((always_inline)) {
-      const int rt = t % C::NBUF, rn = (t + 1) % C::NBUF, rp = (t + C::NBUF - 1) % C::NBUF;
+    auto tile_step = [&](int t, int rt, auto mode_tag, auto pst_tag) __attribute__((always_inline)) {   // rt = t % NBUF (kept by the caller)
+      constexpr int MODE = decltype(mode_tag)::value;
+      using OwnSt = std::integral_constant<int, MODE == 0 ? 0 : (MODE == 3 ? 2 : 1)>;   // what a block of this tile is to its successor
+      const int rn = rt + 1 == C::NBUF ? 0 : rt + 1, rp = rt == 0 ? C::NBUF - 1 : rt - 1;
+      const int lds0 = (int)lds_addr_of(smem);   // inside the opaque bases: otherwise every address costs a second add
       // per-lane bases of this tile's K and V images, of the next tile's K image and of the previous tile's last V fragment
       // (the very first iteration has no previous key block -- its P is 0 -- but must read a FINITE image: ring slot
       // NBUF - 1 has not been written yet and uninitialised LDS may hold NaN patterns, so it reads this tile's own)
-      int kA[C::KS], kN[C::KS], vA[2][C::DB], vP[2];
+      int kA[C::KS], vA[2][C::DB], vP[2];
+      const int kdelta = (rn - rt) * C::TILE_BYTES;   // next tile's K image relative to this one's (one add per read, last iteration only)
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        kA[ks] = opaque(k_off[ks] + rt * C::TILE_BYTES);
-        kN[ks] = opaque(k_off[ks] + rn * C::TILE_BYTES);
+        kA[ks] = opaque(lds0 + k_off[ks] + rt * C::TILE_BYTES);
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
 #pragma unroll
-        for (int db = 0; db < C::DB; ++db) vA[e][db] = opaque(v_off[e][db] + C::V_BASE + rt * C::TILE_BYTES);
-        vP[e] = opaque(v_off[e][C::DB - 1] + C::V_BASE + (t == 0 ? rt * C::TILE_BYTES
+        for (int db = 0; db < C::DB; ++db) vA[e][db] = opaque(lds0 + v_off[e][db] + C::V_BASE + rt * C::TILE_BYTES);
+        vP[e] = opaque(lds0 + v_off[e][C::DB - 1] + C::V_BASE + (t == 0 ? rt * C::TILE_BYTES
                                                                   : rp * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB) + 16 * C::ROWB);
       }
       auto hook = [&](int J, int s) __attribute__((always_inline)) {
@@ -282,20 +332,20 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
           if (s == 1) commit();   // before the first read of tile t + 1 (slot 2), after every read of tile t - 1
 #pragma unroll
           for (int j = 0; j < C::PIECES; ++j)
-            if (s == C::NSS + 1 + 2 * j) dma_pair(t + C::NBUF - 1, j);   // into the buffer tile t - 1 has just left
+            if (s == C::NSS + 1 + 2 * j) dma_pair(t + C::NBUF - 1, rp, j);   // into the buffer tile t - 1 has just left
         }
       };
       auto go = [&](auto j_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value;
         constexpr int kPrevImm = (J - 1) * 32 * C::ROWB + 16 * C::ROWB;   // J > 0: the previous key block lies in this tile
         if constexpr (J == 0)
-          block_iter(j_tag, std::integral_constant<int, 0>{}, mask_tag, t * C::BN, kA, 32 * C::ROWB, vA, 0, vP[0], vP[1], 0, hook);
+          block_iter(j_tag, std::integral_constant<int, 0>{}, mode_tag, pst_tag, t * C::BN, kA, 0, kA, 0, 32 * C::ROWB, vA, 0, vP[0], vP[1], 0, hook);
         else if constexpr (J + 1 < C::NKB)
-          block_iter(j_tag, std::integral_constant<int, J & 1>{}, mask_tag, t * C::BN + 32 * J, kA, (J + 1) * 32 * C::ROWB, vA,
-                     J * 32 * C::ROWB, vA[0][C::DB - 1], vA[1][C::DB - 1], kPrevImm, hook);
+          block_iter(j_tag, std::integral_constant<int, J & 1>{}, mode_tag, OwnSt{}, t * C::BN + 32 * J, kA, J * 32 * C::ROWB, kA, 0,
+                     (J + 1) * 32 * C::ROWB, vA, J * 32 * C::ROWB, vA[0][C::DB - 1], vA[1][C::DB - 1], kPrevImm, hook);
         else
-          block_iter(j_tag, std::integral_constant<int, J & 1>{}, mask_tag, t * C::BN + 32 * J, kN, 0, vA, J * 32 * C::ROWB,
-                     vA[0][C::DB - 1], vA[1][C::DB - 1], kPrevImm, hook);
+          block_iter(j_tag, std::integral_constant<int, J & 1>{}, mode_tag, OwnSt{}, t * C::BN + 32 * J, kA, J * 32 * C::ROWB, kA, kdelta, 0,
+                     vA, J * 32 * C::ROWB, vA[0][C::DB - 1], vA[1][C::DB - 1], kPrevImm, hook);
       };
       go(std::integral_constant<int, 0>{});
       go(std::integral_constant<int, 1>{});
@@ -328,16 +378,21 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         // a row that sees no key at all (rows past S_q) keeps a finite constant: its P is 0 everywhere, O is never stored
         const float m = half_max(mx[rb]);
         mrow[rb] = m > -INFINITY ? m : 0.f;
-        nmc[rb] = -mrow[rb] * c2;
+        nmc[rb] = FOLD ? -mrow[rb] : -mrow[rb] * c2;   // FOLD: scores are in log2 units already
+        if constexpr (CHAIN_M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) negm[rb][i] = -mrow[rb];
+          for (int i = 0; i < 16; ++i) negm[rb][i] = -mrow[rb];
+        }
       }
     };
 
     for (int attempt = 0; attempt < 2; ++attempt) {
       // ---- prologue: the first NBUF - 1 tiles on their way, tile 0 landed ----
+      if (!primed) {
 #pragma unroll
-      for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+        for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+      }
+      primed = false;
       asm volatile("" ::: "memory");
       // tile 0 = the oldest 2 * PIECES pieces: leave the later tiles' pieces in flight
       __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
@@ -384,19 +439,50 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         for (int db = 0; db < C::DB; ++db)
 #pragma unroll
           for (int i = 0; i < 16; ++i) oacc[rb][db][i] = 0.f;
-        thr[1][rb] = 1 << 20;   // nothing of the neutral block is masked (its arguments are -inf already)
+        thr[0][rb] = thr[1][rb] = 1 << 20;   // neutral: nothing is masked (plain blocks never touch their threshold)
       }
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) KF[ks] = lds_read16(smem + k_off[ks]);
+      for (int ks = 0; ks < KR; ++ks) KF[ks] = lds_read16(smem + k_off[ks]);
 #pragma unroll
       for (int pp = 0; pp < 2 * C::DB; ++pp) VF[pp] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
       __builtin_amdgcn_sched_barrier(0);
 
-      int t = 0;
-      for (; t < nplain; ++t) tile_step(t, std::false_type{});
-      for (; t < ntiles; ++t) tile_step(t, std::true_type{});
-      // the set of the last block: NKB is even, so it is always set 1 -> the drain's "previous" set is 1
-      drain(std::integral_constant<int, 0>{}, std::true_type{}, ntiles - 1);
+      int t = 0, rt = 0;
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
+      for (; t < nplain; ++t, rt = rt + 1 == C::NBUF ? 0 : rt + 1) tile_step(t, rt, I0{}, I0{});
+      // The tiles level with the query tile (causal) and / or the ragged last tile.  A tile wholly inside S_k that lies in
+      // the first half of the 256 keys level with the query tile masks row block 0 only (mode 2), one in the second half
+      // has no row block 0 at all (mode 3); anything else masks both row blocks element-wise (mode 1).
+      // The common causal case -- all 256 keys exist -- is written out straight-line: tile variants selected in a loop
+      // merge control flow after every tile, and hipcc reconciles the register assignment of everything live (64-128
+      // accumulator registers) with v_accvgpr_mov at each merge.
+      constexpr int RT = 256 / C::BN;   // region tiles (2 or 4), half of them per mode
+      auto nxt = [](int x) __attribute__((always_inline)) { return x + 1 == C::NBUF ? 0 : x + 1; };
+      // (a masked tile treats its predecessor as masked too -- a plain predecessor carries the neutral threshold: fewer
+      //  variants, and each variant costs registers in ALL paths, hipcc keeps one assignment of the pipeline state)
+      if constexpr (CAUSAL) {
+        // the launcher sends a causal shape here only if every query tile has all 256 keys level with it (S_k a multiple
+        // of 256 and >= the padded S_q): no ragged tile, no generic path -- and fewer variants to keep registers for
+        if constexpr (RT == 2) {
+          tile_step(t, rt, I2{}, I1{});
+          tile_step(t + 1, nxt(rt), I3{}, I1{});
+        } else {
+          tile_step(t, rt, I2{}, I1{});
+          tile_step(t + 1, nxt(rt), I2{}, I1{});
+          tile_step(t + 2, nxt(nxt(rt)), I3{}, I1{});
+          tile_step(t + 3, nxt(nxt(nxt(rt))), I3{}, I2{});
+        }
+        drain(I0{}, I2{}, ntiles - 1);
+      } else {
+        // a ragged last tile masks both row blocks element-wise (a tile treats its predecessor as masked too: a plain
+        // predecessor carries the neutral threshold)
+        for (; t < ntiles; ++t, rt = nxt(rt)) tile_step(t, rt, I1{}, I1{});
+        // the set of the last block: NKB is even, so it is always set 1 -> the drain's "previous" set is 1
+        drain(I0{}, I1{}, ntiles - 1);
+      }
 
       // ---- end-of-pass check: every row sum finite and below the limit, for the whole workgroup ----
       float lt[2];
@@ -407,25 +493,30 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         bad = bad || !(lt[rb] <= Fwd4Limit<T>::value);
       }
       FA_LDS int* flag = (FA_LDS int*)(smem + C::FLAG_OFF);
-      __builtin_amdgcn_s_waitcnt(0x0070);   // every DMA of the pass retired (the ring is reused below)
-      __syncthreads();
-      if (tid == 0) *flag = 0;
-      __syncthreads();
       if (attempt == 0 && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *flag = 1;
+      __builtin_amdgcn_s_waitcnt(0x0070);   // every DMA of the pass retired (the ring is reused below), the flag written
       __syncthreads();
       const int redo = __builtin_amdgcn_readfirstlane(*flag);
       if (!redo) {
-        // ---- epilogue: O = o / l (rows of the ring are free: every wave is past the barrier above) ----
+        if (pass + 1 < npass) {   // the next pass streams the same K/V tiles: on their way during this epilogue
+#pragma unroll
+          for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+          primed = true;
+        }
+        // ---- epilogue: O = o / l, staged in ring slot NBUF - 1 (K image for waves 0-1, V image for waves 2-3), which the
+        // next pass's DMA reaches only after its first commit -- every wave is past its epilogue by then
+        FA_LDS char* stage = smem + (wave >> 1) * C::V_BASE + (C::NBUF - 1) * C::TILE_BYTES + (wave & 1) * 32 * C::ROWB;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const float inv = lt[rb] > 0.f ? 1.0f / lt[rb] : 0.f;
-          store_tile_rows<D, T>(oacc[rb], inv, smem + (wave * 2 + rb) * 32 * C::ROWB, ro, (qw + 32 * rb) * o_rs, lane, o_rs);
+          store_tile_rows<D, T>(oacc[rb], inv, stage, ro, qrow(rb) * o_rs, lane, o_rs);
           if (h == 0)
-            buf_store_f32(rl, (qw + 32 * rb + r) * 4, mrow[rb] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt[rb]));
+            buf_store_f32(rl, (qrow(rb) + r) * 4, mrow[rb] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt[rb]));
         }
         break;
       }
       __syncthreads();
+      if (tid == 0) *flag = 0;   // (ordered before the second attempt's check by the barriers of its sweep)
     }  // attempt
   }  // pass
 }
@@ -441,6 +532,8 @@ static hipError_t launch4(const FwdParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// (fa_kernels.h pick_fwd_impl sends only shapes this family takes: fixed-length launches; causal ones only when every
+// 256-row query tile has all the 256 keys level with it)
 hipError_t launch_fwd_v4(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
   p.nq_tiles = (p.Sq + 255) / 256;
   p.pair = causal != 0;

@@ -170,7 +170,9 @@ inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int
   int f = forced ? forced : table_family(kKernelFwd, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
   if (f == 2 && (D != 64 || !fixed_length)) f = 1;
   if (f == 3 && D != 64) f = 1;
-  if (f == 4 && !fixed_length) f = 1;
+  // family 4: fixed length; causal launches only when every 256-row query tile has all 256 keys level with it (its causal
+  // kernel has no ragged-tile path: fa_fwd_v4.hip)
+  if (f == 4 && (!fixed_length || (causal && !(Sk % 256 == 0 && Sk >= (Sq + 255) / 256 * 256)))) f = 1;
   return (f >= 2 && f <= 4) ? f : 1;
 }
 inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
