@@ -67,13 +67,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
   using C = Fwd4Cfg<D>;
   using vec8 = typename T::vec8;
   constexpr bool FOLD = T::kFoldScale;
-  // the score chains start from -m (a 16-register block per row block) where vector issue is the bound (D = 64); at
-  // D = 128 the matrix pipe is, registers are short, and one subtraction per element is free: chains start from 0
-#ifdef FA_FWD4_CHAIN_ALL   // A/B hook
+  // the score chains start from -m (a 16-register block per row block) wherever the scale is folded into Q (bf16); at
+  // D = 128, where registers are short, one subtraction per element instead measured -5 % (A/B, round 3): kept
   constexpr bool CHAIN_M = FOLD;
-#else
-  constexpr bool CHAIN_M = FOLD && D == 64;
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
 

@@ -57,7 +57,7 @@ def test_library_contains_the_expected_kernels():
     ks = codeobj.kernels()
     names = " ".join(k["name"] for k in ks)
     for stem in ("fa_fwd_kernel", "fa_fwd2_kernel", "fa_fwd3_kernel", "fa_bwd_dq_kernel", "fa_bwd_dq2_kernel", "fa_bwd_dq3_kernel",
-                 "fa_bwd_dkv_kernel", "fa_bwd_dkv2_kernel", "fa_bwd_dkv3_kernel"):
+                 "fa_bwd_dkv_kernel", "fa_bwd_dkv2_kernel", "fa_bwd_dkv3_kernel", "fa_fwd4_kernel"):
         assert stem in names, stem
     assert len(ks) >= 40
     assert all(k["wg"] == 256 for k in ks)
@@ -82,7 +82,7 @@ def test_register_budgets_match_the_intended_occupancy():
             assert total <= (512 if "dkv_kernelILi128E" in n else 256), (n, total)
         elif "fa_fwd_kernelILi64E" in n or "fa_bwd_dq_kernelILi64ENS_4BF16ELb1ELi3E" in n or "fa_bwd_dq_kernelILi64ENS_4BF16ELb0ELi3E" in n:
             assert total <= 168, (n, total)
-        elif "dkv_kernelILi128E" in n or "dkv2_kernelILi128E" in n or "fa_bwd_dkv3_kernel" in n:   # one workgroup per CU
+        elif "dkv_kernelILi128E" in n or "dkv2_kernelILi128E" in n or "fa_bwd_dkv3_kernel" in n or "fa_fwd4_kernel" in n:   # one workgroup per CU
             assert total <= 512, (n, total)
         else:
             assert total <= 256, (n, total)

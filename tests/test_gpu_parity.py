@@ -24,7 +24,7 @@ def _host():
     return M
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "family1", "family2", "family3"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["auto", "family1", "family2", "family3", "family4"])
 def impl(request):
     """Run a test under the automatic schedule rule and with each schedule family forced (a family a launch cannot use
     -- head dim 128 for the D = 64-only families, packed batches for the 64-rows-per-wave forward -- falls back)."""

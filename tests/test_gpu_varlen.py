@@ -18,7 +18,7 @@ def _M():
     return M
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "family1", "family2", "family3"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["auto", "family1", "family2", "family3", "family4"])
 def impl(request):
     import _mi355fa as fa
     fn = fa.lib.fa_debug_force_impl
@@ -107,6 +107,8 @@ def test_equal_length_varlen_is_bit_identical_to_the_fixed_length_kernels(dtype,
     import _mi355fa_torch as ext
     if impl == 2:   # packed rows always take family 1 for forward / dQ (like strided views): pin the fixed-length twin too
         fa.lib.fa_debug_force_impl(1, 1, 2)
+    if impl == 4:   # ... and family 4 (forward only) takes fixed-length launches only
+        fa.lib.fa_debug_force_impl(1, 1, 1)
     B, H, S = 3, 2, 320
     torch.manual_seed(5)
     Qp, Kp, Vp, dOp = (torch.randn(B * S, H, D, device="cuda", dtype=dtype) for _ in range(4))
