@@ -71,7 +71,11 @@ int fa_bwd_dq(const void* q, const void* k, const void* v, const void* o, const 
               int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,
               void* stream);
 
-/* dK and dV; `delta` is the buffer fa_bwd_dq filled. */
+/* dK and dV; `delta` is the buffer fa_bwd_dq filled.
+ * bf16 accuracy note: this plain pair has no workspace, so the dK/dV launch rounds its own scaled operand (K) -- dK / dV
+ * then carry a relative error of about 4.5e-4 * max|score * scale * log2 e| (nothing on ordinary activations, 2 % at 45).
+ * The DOCUMENTED backward call is fa_bwd_dq_ex + fa_bwd_dkv_ex with mi355fa_opts.q_scaled (below):
+ * same cost, dK / dV as accurate as O and dQ at any magnitude.  fp16 is exact either way. */
 int fa_bwd_dkv(const void* q, const void* k, const void* v, const void* dout,
                const float* lse, const float* delta, void* dk, void* dv,
                int B, int H, int S_q, int S_k, int D, int dtype, int causal, float scale,

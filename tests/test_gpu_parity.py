@@ -48,8 +48,9 @@ def run_gpu(Q, K, V, dO, causal):
     return {"O": o.detach().cpu(), "dQ": q.grad.cpu(), "dK": k.grad.cpu(), "dV": v.grad.cpu()}
 
 
-def run_gpu_raw(Q, K, V, dO, causal):
-    """The launchers directly: also returns LSE and delta (not visible through autograd)."""
+def run_gpu_raw(Q, K, V, dO, causal, workspace=False):
+    """The launchers directly: also returns LSE and delta (not visible through autograd).  workspace=True: the backward as
+    INTEGRATION.md section B binds it -- fa_bwd_dq_ex / fa_bwd_dkv_ex with mi355fa_opts.q_scaled -- through raw ctypes."""
     M = _host()
     q, k, v, do = (x.cuda() for x in (Q, K, V, dO))
     O, LSE = M.flash_attention_forward(q, k, v, causal)
@@ -60,6 +61,18 @@ def run_gpu_raw(Q, K, V, dO, causal):
     delta = torch.empty_like(LSE)
     st = torch.cuda.current_stream().cuda_stream
     dt = M._DTYPES[q.dtype]
+    if workspace:
+        import ctypes
+        ws = torch.empty_like(q)
+        o = fa.Opts.make(q_scaled=ws.data_ptr())
+        fa.check(fa.lib.fa_bwd_dq_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), O.data_ptr(), do.data_ptr(), LSE.data_ptr(),
+                                     dQ.data_ptr(), delta.data_ptr(), B, H, Sq, Sk, D, dt, int(causal), D ** -0.5,
+                                     ctypes.byref(o), st), "dq_ex")
+        fa.check(fa.lib.fa_bwd_dkv_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(), LSE.data_ptr(), delta.data_ptr(),
+                                      dK.data_ptr(), dV.data_ptr(), B, H, Sq, Sk, D, dt, int(causal), D ** -0.5,
+                                      ctypes.byref(o), st), "dkv_ex")
+        torch.cuda.synchronize()
+        return {k_: t.cpu() for k_, t in dict(O=O, LSE=LSE, delta=delta, dQ=dQ, dK=dK, dV=dV).items()}
     fa.check(fa.lib.fa_bwd_dq(q.data_ptr(), k.data_ptr(), v.data_ptr(), O.data_ptr(), do.data_ptr(), LSE.data_ptr(),
                               dQ.data_ptr(), delta.data_ptr(), B, H, Sq, Sk, D, dt, int(causal), D ** -0.5, st), "dq")
     fa.check(fa.lib.fa_bwd_dkv(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(), LSE.data_ptr(), delta.data_ptr(),
@@ -266,6 +279,12 @@ def test_large_magnitude_scores_bf16_with_the_scaled_q_workspace(causal):
     for name, got in (("dK", k.grad), ("dV", v.grad)):   # and it is the workspace that does it
         assert fo.rel_fro(gt[name], got.cpu()) < 0.6 * fo.rel_fro(gt[name], raw[name]), name
     assert torch.equal(o.detach().cpu(), raw["O"]) and torch.equal(q.grad.cpu(), raw["dQ"])
+    # the same bound through the C entry points INTEGRATION.md section B tells a maintainer to bind
+    # (fa_bwd_dq_ex / fa_bwd_dkv_ex with q_scaled, raw ctypes) -- bit for bit what flash_attention() computed
+    bound = run_gpu_raw(Q, K, V, dO, causal, workspace=True)
+    for name, got in (("dQ", q.grad), ("dK", k.grad), ("dV", v.grad)):
+        assert torch.equal(bound[name], got.cpu()), name
+        assert fo.rel_fro(gt[name], bound[name]) < max(2.5 * fo.rel_fro(gt[name], peer[name]), 6e-3), name
 
 
 # ---------------------------------------------------------------- (3) torch SDPA on the device

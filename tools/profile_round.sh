@@ -2,9 +2,9 @@
 # Round profile bundle (run on the GPU box through gpurun): PMC passes of the three kernels and the gfx950-corrected HBM
 # traffic tied to the kernel source hash FIRST (so that the bench lines of the same run carry roofline.traffic), then the
 # bench lines and the rocprofv3 kernel stats of the same bench command.
-#   tools/profile_round.sh r02      -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
+#   tools/profile_round.sh r03      -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 tools/pmc.sh $OUT/${TAG}_pmc > /dev/null 2>&1 || true
