@@ -53,7 +53,7 @@ def measure(out_path, rounds, reps, min_ms, only=None):
             code = host.BF16 if dtype == "bf16" else host.FP16
             for bh in BH_BUCKETS:
                 for S in S_BUCKETS:
-                    if bh * S * S > 128 * 16384 * 16384 // 16 or bh * S > 512 * 4096:   # keep a point under ~20 ms
+                    if bh * S * S > 512 * 8192 * 8192 or bh * S > 512 * 8192:   # up to BASELINE config 5's size (~30 ms a launch)
                         continue
                     H = 8 if bh >= 8 else bh
                     B = bh // H
