@@ -52,8 +52,17 @@ struct Fwd4Cfg {
   static constexpr int LDS_BYTES = FLAG_OFF + 16;
   static constexpr int PIECES = TILE_BYTES / (NW * 1024);   // 1-KiB LDS-DMA pieces per wave per matrix (4)
   static constexpr int RPI = 1024 / ROWB;                   // tile rows per piece
-  static constexpr int NSS = 2 * KS, NPV = 4 * DB, NSLOT = NSS + NPV;   // MFMA slots of one block iteration
-  static constexpr int EPS = 32 / NSLOT;                    // exps per slot (2 or 1)
+  // A/B hook, OFF: row sums on the MATRIX pipe (l^T += 1^T P^T: one more MFMA per (k-step, row block) with an all-ones A
+  // fragment, 4 per block iteration at D = 64) instead of 32 row-sum adds.  By issue arithmetic a clear win at D = 64 (~140
+  // vector-issue cycles saved per iteration for 32 of MFMA issue, and the matrix pipe is only ~60 % busy); by WALL it loses:
+  // B4 H32 N4096 bf16 non-causal 0.508 vs 0.487 ms, causal 0.283 vs 0.280 ms (interleaved A/B, round 3) -- 25 % more MFMA
+  // work costs more clock (the chip is power-limited) than the adds cost issue slots.
+#ifndef FA_FWD4_LSUM_MFMA
+#define FA_FWD4_LSUM_MFMA 0
+#endif
+  static constexpr bool LSUM = FA_FWD4_LSUM_MFMA && D == 64;
+  static constexpr int PVG = 2 * DB + (LSUM ? 2 : 0);       // slots per k-step of the P V phase: (d block, row block) pairs [+ row sums]
+  static constexpr int NSS = 2 * KS, NPV = 2 * PVG, NSLOT = NSS + NPV;   // MFMA slots of one block iteration
   static constexpr int INFLIGHT = (NBUF - 3) * 2 * PIECES;  // pieces of later tiles a commit leaves in flight (vmcnt)
 };
 
@@ -192,36 +201,43 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
     u32x4 KF[KR];           // K row fragments of the key block being scored
     vec8 VF[2 * C::DB];     // V^T fragments (k-step e, d block db) -> index e * DB + db of the key block being multiplied
     f32x16 oacc[2][C::DB];
+    f32x16 lacc[C::LSUM ? 2 : 1];   // LSUM: row sums as an MFMA accumulator (every register of a lane holds its row's sum)
+    const unsigned one2 = std::is_same<T, BF16>::value ? 0x3F803F80u : 0x3C003C00u;   // two 16-bit ones
+    const u32x4 ones = {one2, one2, one2, one2};
     int thr[2][2];   // [set][row block]: mask threshold of a block; plain blocks leave the neutral 1 << 20 of the fill (masks nothing)
 
     // VALU work of ONE key block at pipeline time tau (slots since the start of its own iteration): exps q = 0..31 in the
-    // order rb0[0..7], rb1[0..7], rb0[8..15], rb1[8..15], EPS per slot from tau = NSS on; the row-sum add of a value and
-    // the pack of a pair follow ONE SLOT later (the last ones at tau = NSLOT + NSS, before the first P V MFMA that needs them).
+    // order rb0[0..7], rb1[0..7], rb0[8..15], rb1[8..15], spread evenly over the NSLOT slots from tau = NSS on; the row-sum
+    // add of a value and the pack of a pair follow ONE SLOT later (the last at tau = NSLOT + NSS, before the MFMA that needs it).
     auto block_valu = [&](int tau, f32x16 (&X)[2], u32x4 (&PK)[2][2], const int (&TH)[2], auto mask_tag, auto has0_tag) __attribute__((always_inline)) {
       constexpr bool MASK = decltype(mask_tag)::value, HAS0 = decltype(has0_tag)::value;   // HAS0: row block 0 takes part
+      // exp q issues at slot NSS + q * NSLOT / 32 (the 32 exps spread evenly over one iteration): the q of a slot are
+      // [ceil(32 (tau - NSS) / NSLOT), ceil(32 (tau - NSS + 1) / NSLOT)), at most two
+      auto first_q = [](int t) { return t <= 0 ? 0 : (32 * t + C::NSLOT - 1) / C::NSLOT; };
+      auto work = [&](int t, bool exps) __attribute__((always_inline)) {   // t = tau - NSS of the exps concerned
+        if (t < 0 || t >= C::NSLOT) return;
 #pragma unroll
-      for (int u = 0; u < C::EPS; ++u) {
-        const int q = (tau - C::NSS) * C::EPS + u;
-        if (q < 0 || q >= 32) continue;
-        const int rb = (q >> 3) & 1, e = (q & 7) + 8 * (q >> 4);
-        if (rb == 0 && !HAS0) continue;
-        float x = CHAIN_M ? X[rb][e] : (FOLD ? X[rb][e] + nmc[rb] : __builtin_fmaf(X[rb][e], c2, nmc[rb]));
-        if constexpr (MASK) x = (e & 3) + 8 * (e >> 2) > TH[rb] ? -INFINITY : x;
-        X[rb][e] = __builtin_amdgcn_exp2f(x);
-      }
-      // row sums and packs of the PREVIOUS slot's exps: a transcendental's result is not there for the next instruction
-#pragma unroll
-      for (int u = 0; u < C::EPS; ++u) {
-        const int q = (tau - 1 - C::NSS) * C::EPS + u;
-        if (q < 0 || q >= 32) continue;
-        const int rb = (q >> 3) & 1, e = (q & 7) + 8 * (q >> 4);
-        if (rb == 0 && !HAS0) continue;
-        l[rb] += X[rb][e];
-        if (q & 1) {
-          const int j = e >> 1;   // pair (e - 1, e)
-          PK[rb][j >> 2][j & 3] = pack2<T>(X[rb][e - 1], X[rb][e]);
+        for (int u = 0; u < 2; ++u) {
+          const int q = first_q(t) + u;
+          if (q >= first_q(t + 1) || q >= 32) continue;
+          const int rb = (q >> 3) & 1, e = (q & 7) + 8 * (q >> 4);
+          if (rb == 0 && !HAS0) continue;
+          if (exps) {
+            float x = CHAIN_M ? X[rb][e] : (FOLD ? X[rb][e] + nmc[rb] : __builtin_fmaf(X[rb][e], c2, nmc[rb]));
+            if constexpr (MASK) x = (e & 3) + 8 * (e >> 2) > TH[rb] ? -INFINITY : x;
+            X[rb][e] = __builtin_amdgcn_exp2f(x);
+          } else {
+            if constexpr (!C::LSUM) l[rb] += X[rb][e];
+            if (q & 1) {
+              const int j = e >> 1;   // pair (e - 1, e)
+              PK[rb][j >> 2][j & 3] = pack2<T>(X[rb][e - 1], X[rb][e]);
+            }
+          }
         }
-      }
+      };
+      work(tau - C::NSS, true);
+      // row sums (unless the matrix pipe takes them) and packs ONE SLOT later: a transcendental's result is not there for the next instruction
+      work(tau - 1 - C::NSS, false);
     };
     // LDS addresses are `per-lane base register (set once per tile, opaque to hipcc) + immediate`: left alone, hipcc hoists
     // every (lane offset + constant) pair out of the tile loop -- thirty values parked in AGPRs and ~100 vector instructions
@@ -256,9 +272,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
               T::mfma_v_acc(S_[SET][rb], KF[ks % KR], qf[rb][ks]);
             }
           }
-        } else {   // P V of the previous key block: (k-step e, d block db) = (pp / DB, pp % DB), row block n & 1
-          const int n = s - C::NSS, rb = n & 1, pp = n >> 1, e = pp / C::DB, db = pp % C::DB;
-          if (rb == 1 || PREV0) oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
+        } else {   // the previous key block, k-step e: P V for (d block, row block) pairs, then (LSUM) the two row sums
+          const int n = s - C::NSS, e = n / C::PVG, m = n % C::PVG, rb = m & 1;
+          if (rb == 1 || PREV0) {
+            if (m < 2 * C::DB) oacc[rb][m >> 1] = T::mfma(VF[e * C::DB + (m >> 1)], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][m >> 1]);
+            else lacc[rb] = T::mfma(as_vec8<T>(ones), as_vec8<T>(pk[PSET][rb][e]), lacc[rb]);
+          }
         }
         // ---- LDS reads into registers whose last use is just over ----
         if (s >= 2 && s <= C::NSS && (s & 1) == 0) {
@@ -268,13 +287,16 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
           if (nk < C::KS) KF[ks % KR] = lds_read16(lds_at(kc[nk] + kc_imm));
           else KF[ks % KR] = lds_read16(lds_at(kn[nk - C::KS] + kn_delta + kn_imm));
         }
-        if (s >= C::NSS + 2 && ((s - C::NSS) & 1) == 0) {   // V^T fragment of THIS key block (multiplied in the next iteration)
-          const int pp = (s - C::NSS - 2) >> 1, e = pp / C::DB, db = pp % C::DB;
-          VF[pp] = lds_read_tr_frag<T>(lds_at(vc[0][db] + vc_imm + 16 * e * C::ROWB), lds_at(vc[1][db] + vc_imm + 16 * e * C::ROWB));
-        }
-        if (s == 0) {   // the last V^T fragment (k-step 1, last d block) of the PREVIOUS key block: its register was busy until the last slot
-          constexpr int pp = 2 * C::DB - 1;
-          VF[pp] = lds_read_tr_frag<T>(lds_at(vp0 + vp_imm), lds_at(vp1 + vp_imm));
+        // V^T fragment (e, db) of THIS key block (multiplied in the next iteration) goes into its register right after the
+        // last MFMA that read the old content (slot NSS + e PVG + 2 db + 1); only without LSUM does the very last one fall
+        // off the end of the iteration -- it is then read at slot 0 of the next one, from the PREVIOUS key block's image
+#pragma unroll
+        for (int pp = 0; pp < 2 * C::DB; ++pp) {
+          const int e = pp / C::DB, db = pp % C::DB, at = C::NSS + e * C::PVG + 2 * db + 2;
+          if (at < C::NSLOT && s == at)
+            VF[pp] = lds_read_tr_frag<T>(lds_at(vc[0][db] + vc_imm + 16 * e * C::ROWB), lds_at(vc[1][db] + vc_imm + 16 * e * C::ROWB));
+          if (at >= C::NSLOT && s == 0)
+            VF[pp] = lds_read_tr_frag<T>(lds_at(vp0 + vp_imm), lds_at(vp1 + vp_imm));
         }
         // ---- VALU: the previous key block at tau = NSLOT + s, this one at tau = s ----
         block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], PrevMask{}, std::integral_constant<bool, PREV0>{});
@@ -286,15 +308,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
     auto drain = [&](auto set_tag, auto pst_tag, int t_last) __attribute__((always_inline)) {
       constexpr int PSET = decltype(set_tag)::value ^ 1, PST = decltype(pst_tag)::value;
       constexpr bool PREV0 = PST != 2;
-      {   // the last V^T fragment of the last key block (read at slot 0 of the following iteration in the steady state)
+      if constexpr (!C::LSUM) {   // the last V^T fragment of the last key block (slot 0 of the following iteration in the steady state)
         const int base = C::V_BASE + (t_last % C::NBUF) * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB + 16 * C::ROWB;
         VF[2 * C::DB - 1] = lds_read_tr_frag<T>(smem + v_off[0][C::DB - 1] + base, smem + v_off[1][C::DB - 1] + base);
       }
 #pragma unroll
       for (int s = 0; s < C::NSLOT; ++s) {
         if (s >= C::NSS) {
-          const int n = s - C::NSS, rb = n & 1, pp = n >> 1, e = pp / C::DB, db = pp % C::DB;
-          if (rb == 1 || PREV0) oacc[rb][db] = T::mfma(VF[pp], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][db]);
+          const int n = s - C::NSS, e = n / C::PVG, m = n % C::PVG, rb = m & 1;
+          if (rb == 1 || PREV0) {
+            if (m < 2 * C::DB) oacc[rb][m >> 1] = T::mfma(VF[e * C::DB + (m >> 1)], as_vec8<T>(pk[PSET][rb][e]), oacc[rb][m >> 1]);
+            else lacc[rb] = T::mfma(as_vec8<T>(ones), as_vec8<T>(pk[PSET][rb][e]), lacc[rb]);
+          }
         }
         block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], std::integral_constant<bool, PST != 0>{}, std::integral_constant<bool, PREV0>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -428,13 +453,22 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       for (int rb = 0; rb < 2; ++rb) {
         l[rb] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) S_[1][rb][i] = i < 8 ? 0.f : -INFINITY;   // elements 0-7 "done" (P = 0), 8-15 give exp2(-inf)
+        for (int i = 0; i < 16; ++i) {
+          // an element whose exp belongs to the block's own iteration (slot < NSLOT) is "done" (P = 0); the others are
+          // still exponent arguments when the next iteration takes over: exp2(-inf) = 0
+          const int q = (i >> 3) * 16 + rb * 8 + (i & 7);
+          S_[1][rb][i] = C::NSS + q * C::NSLOT / 32 < C::NSLOT ? 0.f : -INFINITY;
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) pk[1][rb][e] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int db = 0; db < C::DB; ++db)
 #pragma unroll
           for (int i = 0; i < 16; ++i) oacc[rb][db][i] = 0.f;
+        if constexpr (C::LSUM) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lacc[rb][i] = 0.f;
+        }
         thr[0][rb] = thr[1][rb] = 1 << 20;   // neutral: nothing is masked (plain blocks never touch their threshold)
       }
 #pragma unroll
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       bool bad = false;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
-        lt[rb] = half_sum(l[rb]);
+        lt[rb] = C::LSUM ? lacc[C::LSUM ? rb : 0][0] : half_sum(l[rb]);   // LSUM: the MFMA summed over both lane halves' keys already
         bad = bad || !(lt[rb] <= Fwd4Limit<T>::value);
       }
       FA_LDS int* flag = (FA_LDS int*)(smem + C::FLAG_OFF);
