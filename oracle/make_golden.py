@@ -126,11 +126,27 @@ def kats():
     for causal in (False, True):
         o = RP.naive_attention(q, k, v, causal)
         out["naive"].append({"causal": causal, "sum": float(o.sum()), "o": o.flatten().tolist()})
-    for (B, H, S, D, causal) in [(4, 32, 4096, 64, True), (4, 32, 4096, 128, True), (64, 32, 8192, 64, True),
-                                 (2, 4, 256, 64, False), (4, 8, 4096, 64, True)]:
-        f = 4 * B * H * S * S * D // (2 if causal else 1)  # P:101
-        out["flops"].append({"B": B, "H": H, "S": S, "D": D, "causal": causal,
-                             "fwd": f, "bwd": int(2.5 * f), "fwd_bwd": int(3.5 * f)})
+    # FLOP counts from the reference's OWN benchmark_attention (P:9-109), not from a formula restated here:
+    # its return value is (avg_time_ms, tflops) with tflops = k * flops / (avg_time_ms * 1e-3) / 1e12 (P:101-107), so with its
+    # `timing` helper replaced by one that reports exactly 1.0 ms (and runs nothing: there is no GPU here, and its CUDA events
+    # would not construct), flops = tflops * 1e9 to the last integer.  provider='naive' keeps Triton out of the call.
+    real_timing = RP.timing
+    # ('bwd' is timing(fwd+bwd) - timing(fwd), P:95: the stand-in answers 2.0 ms for the former so that the difference is 1.0)
+    RP.timing = lambda run_fn, warmup, repeat: 2.0 if run_fn.__name__ == "run_fn_all" else 1.0
+    try:
+        for (B, H, S, D, causal) in [(4, 32, 4096, 64, True), (4, 32, 4096, 128, True), (64, 32, 8192, 64, True),
+                                     (2, 4, 256, 64, False), (4, 8, 4096, 64, True)]:
+            # the reference allocates its fp16 inputs before anything else; config 5's are 2 GiB each -- a smaller batch
+            # gives the same per-batch count, scaled back up exactly (the count is linear in B, P:101)
+            b = min(B, 4)
+            got = {}
+            for mode in ("fwd", "bwd", "fwd_bwd"):
+                ms, tflops = RP.benchmark_attention("naive", mode, b, H, S, S, D, causal, torch.device("cpu"))
+                assert ms == 1.0
+                got[mode] = round(tflops * 1e9) * (B // b)
+            out["flops"].append({"B": B, "H": H, "S": S, "D": D, "causal": causal, **got})
+    finally:
+        RP.timing = real_timing
     with open(os.path.join(OUT, "kat.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("kat.json:", out["verify"], [x["sum"] for x in out["naive"]])
