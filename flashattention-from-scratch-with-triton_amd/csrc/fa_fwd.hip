@@ -47,8 +47,7 @@ struct FwdCfg {
   static constexpr int DB = D / 32;        // 32-wide d blocks of O^T
   static constexpr int TILE_BYTES = BN * ROWB;
   static constexpr int DMA_PER_MAT = TILE_BYTES / (4 * 1024);  // 1-KiB LDS-DMA instructions per wave per matrix
-  static constexpr int FLAG_OFF = 4 * TILE_BYTES;   // one word: a wave's row sums left the safe range (bf16 first attempt)
-  static constexpr int LDS_BYTES = 4 * TILE_BYTES + 16;  // K[2], V[2], flag
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2], V[2]
 };
 
 // Online-softmax rescale is deferred until a row max grows by more than 2^kDeferLog2 (see tile()).
@@ -85,7 +84,6 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   const int nq = (Sq + C::BM - 1) / C::BM;
   if (idx >= (paired ? (nq + 1) / 2 : nq)) return;
   const int npass = (paired && idx != nq - 1 - idx) ? 2 : 1;
-  if (threadIdx.x == 0) *(FA_LDS int*)(smem + C::FLAG_OFF) = 0;   // ordered before its first use by every pass's tile barriers
   for (int pass = 0; pass < npass; ++pass) {
   // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
   const int lane = lane_id_now(), tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
@@ -331,9 +329,8 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   // MASKED = true: the same for a tile on the causal diagonal or the ragged tail -- dead scores become -inf (p = 0),
   // key blocks no row of the wave can see are skipped.  A wave whose first visible tile is masked arrives here with
   // m = -inf, overflows by construction and takes the exact path once.
-  // ZERO (round 3, bf16 first attempt): no row constant at all -- chains start from 0, nothing is tested (see the main loop).
-  auto tile_lazy = [&](int t, auto masked_tag, auto zero_tag) __attribute__((always_inline)) -> bool {
-    constexpr bool MASKED = decltype(masked_tag)::value, ZERO = decltype(zero_tag)::value;
+  auto tile_lazy = [&](int t, auto masked_tag) __attribute__((always_inline)) -> bool {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
     const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
     const int s0 = t * C::BN;
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
     for (int b = 0; b < 2; ++b) {
       if (MASKED && !use[b]) continue;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[b][i] = (FOLD && !ZERO) ? negm[i] : 0.f;
+      for (int i = 0; i < 16; ++i) sacc[b][i] = FOLD ? negm[i] : 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         vec8 a = as_vec8<T>(lds_read16(kt + k_off[ks] + b * 32 * C::ROWB));
@@ -381,11 +378,9 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
       }
     }
     const float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
-    if constexpr (!ZERO) {
-      if (__builtin_amdgcn_ballot_w64(!(lsum <= kLazySumMax)) != 0) {
-        FA_PRIO_VALU(0);
-        return false;
-      }
+    if (__builtin_amdgcn_ballot_w64(!(lsum <= kLazySumMax)) != 0) {
+      FA_PRIO_VALU(0);
+      return false;
     }
     l += lsum;
     FA_PRIO_VALU(0);
@@ -422,54 +417,6 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   // merge control flow get their accumulators copied at every join.
   int t = 0;
   bool prefetched = false;
-  // bf16, round 3: a first attempt with NO row constant (m = 0).  P = exp2(score) has the exponent range of fp32 in bf16
-  // too, so the number format itself plays the part of the running maximum: no exact first tile, no per-tile overflow
-  // test, no rescale.  The row sums are checked once at the end of the pass; a pass whose sums left [2^-80, 2^100]
-  // (|score * scale * log2 e| of that order: far outside what trained models produce) is redone by the loops below,
-  // exactly as before -- results are exact either way.  (Same idea as fa_fwd_v4.hip; fp16's P has no such range.)
-#ifdef FA_FWD_NO_ZERO_M   // A/B hook
-  constexpr bool ZERO_M = false;
-#else
-  constexpr bool ZERO_M = FOLD && !DROP;
-#endif
-  bool redo = false;
-  if constexpr (ZERO_M) {
-    using Z = std::true_type;
-    m = 0.f;
-    for (; t < nfull; ++t) {
-      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-      tile_lazy(t, std::false_type{}, Z{});
-      tile_sync();
-    }
-    for (; t < ntiles; ++t) {
-      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-      tile_lazy(t, std::true_type{}, Z{});
-      tile_sync();
-    }
-    const float l0 = half_sum(l);
-    // (a sequence without keys has l = 0 and takes the second attempt too: no tiles there either)
-    const bool bad = !(l0 <= 1.2676506e30f /* 2^100 */) || !(l0 >= 8.2718e-25f /* 2^-80 */);
-    FA_LDS int* flag = (FA_LDS int*)(smem + C::FLAG_OFF);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *flag = 1;
-    __syncthreads();
-    redo = __builtin_amdgcn_readfirstlane(*flag) != 0;
-    if (redo) {   // cold: start the pass over on the exact path
-      __syncthreads();
-      if (tid == 0) *flag = 0;
-      m = -INFINITY;
-      l = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) negm[i] = INFINITY;
-#pragma unroll
-      for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
-      t = 0;
-      dma_tile(0, 0);
-      tile_sync();
-    }
-  }
-  if (!ZERO_M || redo) {
   if constexpr (DROP) {  // the lazy path commits P before the mask could be applied consistently: exact tiles only
     for (; t < nfull; ++t) {
       if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
@@ -490,7 +437,7 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
     prefetched = false;
     for (; t < nfull; ++t) {
       if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-      if (!tile_lazy(t, std::false_type{}, std::false_type{})) {
+      if (!tile_lazy(t, std::false_type{})) {
         prefetched = true;
         break;
       }
@@ -501,9 +448,8 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   for (; t < ntiles; ++t) {
     if (!prefetched && t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
     prefetched = false;
-    if (!tile_lazy(t, std::true_type{}, std::false_type{})) tile(t, BR{}, std::true_type{});
+    if (!tile_lazy(t, std::true_type{})) tile(t, BR{}, std::true_type{});
     tile_sync();
-  }
   }
 
   // ---- epilogue ----
