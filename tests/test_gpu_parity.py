@@ -233,6 +233,70 @@ def test_rescale_branch_is_exercised_by_a_late_spike(impl, dtype):
             assert fo.rel_fro(gt["LSE"], r["LSE"]) < 2e-3
 
 
+@pytest.mark.parametrize("dtype", [F16, BF16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("D", [64, 128])
+def test_family4_forward_overflow_takes_the_exact_second_attempt(dtype, D):
+    """Round 3: the one-wave-per-SIMD forward (fa_fwd_v4.hip) keeps ONE row constant per pass (the maximum over the row's
+    first 32 keys) and checks the row sums at the end of the pass; a key far down the sequence that beats that constant by
+    more than the number format allows (2^15 for fp16, 2^100 for bf16) must send the pass through its exact second attempt
+    -- same tolerances as everywhere else, forward only (the backward does not depend on the forward's schedule)."""
+    import ctypes
+    import _mi355fa as fa
+    M = _host()
+    fa.lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+    B, H, S = 1, 2, 768
+    Q, K, V, dO = rand_inputs(B, H, S, S, D, dtype, seed=31)
+    # row 600's score against key 517: |q|^2 * gain / sqrt(D) * log2(e) ~ 2^138+ (bf16) / ~ 2^37+ (fp16) above its first keys'
+    K[0, 0, 517] = (Q[0, 0, 600].float() * (12.0 if dtype == BF16 else 3.2)).to(dtype)
+    K[0, 1, 300] = (Q[0, 1, 700].float() * (12.0 if dtype == BF16 else 3.2)).to(dtype)
+    redo = fa.lib.fa_debug_fwd4_redo_count
+    redo.restype, redo.argtypes = ctypes.c_uint, []
+    for causal in (False, True):
+        gt = fo.attention_fp64(Q, K, V, dO, causal)
+        outs = {}
+        for fam in (1, 4):
+            fa.lib.fa_debug_force_impl(fam, 0, 0)
+            before = redo()
+            try:
+                O, LSE = M.flash_attention_forward(Q.cuda(), K.cuda(), V.cuda(), causal)
+                torch.cuda.synchronize()
+            finally:
+                fa.lib.fa_debug_force_impl(0, 0, 0)
+            took = redo() - before
+            # the two spiked rows sit in two different (head, query tile) workgroups: exactly those redo their pass
+            assert took == (2 if fam == 4 else 0), (fam, causal, took)
+            outs[fam] = (O.cpu(), LSE.cpu())
+            assert torch.isfinite(O.float()).all() and torch.isfinite(LSE).all(), (fam, causal)
+        e1, e4 = fo.rel_fro(gt["O"], outs[1][0]), fo.rel_fro(gt["O"], outs[4][0])
+        assert e4 < max(1.5 * e1, 1e-3 if dtype == F16 else 6e-3), (causal, e1, e4)
+        assert fo.rel_fro(gt["LSE"], outs[4][1]) < max(2 * fo.rel_fro(gt["LSE"], outs[1][1]), 2e-3), causal
+
+
+def test_dkv_family3_is_bit_identical_to_family2():
+    """Round 3: the one-wave-per-SIMD dK/dV kernel (fa_bwd_dkv_v3.hip) keeps the maths, the rounding points and the
+    accumulation order of family 2 -- identical bits, causal and full, both dtypes, ragged and cross-attention shapes
+    (tools/check_family.py runs the long list, incl. the headline shape)."""
+    import ctypes
+    import _mi355fa as fa
+    M = _host()
+    fa.lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+    for dtype in (BF16, F16):
+        for causal in (False, True):
+            for (B, H, Sq, Sk) in ((2, 3, 640, 640), (1, 2, 500, 500), (1, 2, 77, 333), (1, 2, 333, 77), (1, 1, 1024, 256)):
+                Q, K, V, dO = (x.cuda() for x in rand_inputs(B, H, Sq, Sk, 64, dtype, seed=Sq + Sk))
+                O, LSE = M.flash_attention_forward(Q, K, V, causal)
+                got = {}
+                for fam in (2, 3):
+                    fa.lib.fa_debug_force_impl(0, 0, fam)
+                    try:
+                        got[fam] = M.flash_attention_backward(Q, K, V, O, dO, LSE, causal)
+                        torch.cuda.synchronize()
+                    finally:
+                        fa.lib.fa_debug_force_impl(0, 0, 0)
+                for a, b in zip(got[2][1:], got[3][1:]):      # dK, dV
+                    assert torch.equal(a, b), (dtype, causal, Sq, Sk)
+
+
 @pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
 def test_large_magnitude_scores_bf16(impl, causal):
     """Scaled-up Q and K (|s * log2e / sqrt(D)| up to ~50-100): the folded-scale bf16 kernels carry the exponent
