@@ -26,6 +26,11 @@
  *   - causal != 0 applies the top-left aligned mask  key <= query  (K:102);
  *   - any S_q, S_k >= 1 is accepted (tails are masked); D must be 64 or 128.
  *
+ * Reading guide: the boundary is SIX functions -- fa_fwd / fa_bwd_dq / fa_bwd_dkv (the reference's three launches as they
+ * are) and their general forms fa_fwd_ex / fa_bwd_dq_ex / fa_bwd_dkv_ex at the end of this file (strides, packed
+ * variable-length batches, dropout, the bf16 backward workspace, in any combination).  The *_strided, *_varlen and
+ * *_dropout groups in between are one-call conveniences over the _ex forms, kept for callers that need one feature.
+ *
  * Every function returns 0 on success.  A negative value is an argument error detected
  * before anything is launched, a positive value is the hipError_t of the failed launch;
  * fa_last_error() then returns a thread-local, human-readable description.
