@@ -233,9 +233,10 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
             const int i = 4 * g + j;
             const bool keep = ((patch[j] >> (8 * (key & 3))) & 255u) >= dr.thresh;
             const float pe = sacc[i];
-            const float dp = keep ? pacc[i] * dr.rp : 0.f;     // dP = mask / (1 - p) o (dO V^T)
-            pacc[i] = pe * (dp + nd[i]);                       // dS = P o (dP - delta)
-            sacc[i] = keep ? pe * dr.rp : 0.f;                 // dropped, rescaled P for dV
+            // dS = P o (dP - delta) with dP = mask / (1 - p) o (dO V^T): one fma, one select, one multiply
+            const float t = __builtin_fmaf(pacc[i], dr.rp, nd[i]);
+            pacc[i] = pe * (keep ? t : nd[i]);
+            sacc[i] = keep ? pe : 0.f;                         // dropped P for dV (its 1 / (1 - p) is applied once, to dV)
           }
         };
         apply(std::integral_constant<int, 0>{});
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256, (D == 64 ? 2 : 1)) void fa_bwd_dkv_kernel(BwdP
   FA_LDS char* stage = smem + wave * 32 * C::ROWB;
   // dK = dS^T Q * scale; with the pre-scaled Q (= Q * scale * log2e) in LDS that is dS^T Q' * ln 2
     store_tile_rows<D, T>(dkacc, (FOLD && p.q_prescaled) ? kLn2 : p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
-  store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
+  store_tile_rows<D, T>(dvacc, DROP ? p.drop.rp : 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
   }  // pass
 }
 

@@ -233,8 +233,9 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
             const bool keep = ((w >> (8 * j)) & 255u) >= dr.thresh;
-            const float dp = keep ? pacc[i] * dr.rp : 0.f;   // dP = mask / (1 - p) o (dO V^T)
-            sacc[i] = sacc[i] * (dp - delta);                // dS = P o (dP - delta)
+            // dS = P o (dP - delta) with dP = mask / (1 - p) o (dO V^T): one fma, one select, one multiply
+            const float t = __builtin_fmaf(pacc[i], dr.rp, -delta);
+            sacc[i] = sacc[i] * (keep ? t : -delta);
           }
         };
         apply(std::integral_constant<int, 0>{});

@@ -371,7 +371,8 @@ FA_DEVINL u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3
     const unsigned long long p0 = (unsigned long long)kM0 * c0, p1 = (unsigned long long)kM1 * c2;
     const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
     const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    // three-input xor in one instruction (v_bitop3_b32, truth table 0x96); hipcc emits two v_xor_b32 for hi ^ c ^ k
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
     c0 = n0;
     c1 = lo1;
     c2 = n2;
@@ -388,7 +389,9 @@ FA_DEVINL u32x4 dropout_patch(const Dropout& d, int qg, int kg, int bh) {
 // value of `v` in lane G of this lane's quad (all four lanes of the quad must be active: EXEC is full in these kernels)
 template <int G>
 FA_DEVINL unsigned quad_bcast(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, G * 0x55 /* quad_perm:[G,G,G,G] */, 0xF, 0xF, false);
+  // bound_ctrl: every lane of a quad_perm has a valid source, so `old` is never used -- saying so spares the v_mov that
+  // initialises it and lets the DPP operand fold into the consuming instruction
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, G * 0x55 /* quad_perm:[G,G,G,G] */, 0xF, 0xF, true);
 }
 template <int G>
 FA_DEVINL u32x4 quad_bcast4(const u32x4& v) {

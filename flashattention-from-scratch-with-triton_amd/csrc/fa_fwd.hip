@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const bool keep = ((w >> (8 * j)) & 255u) >= dr.thresh;
-            sacc[b][4 * g + j] = keep ? sacc[b][4 * g + j] * dr.rp : 0.f;
+            sacc[b][4 * g + j] = keep ? sacc[b][4 * g + j] : 0.f;   // (the factor 1 / (1 - p) is applied once, to O)
           }
         };
         apply(std::integral_constant<int, 0>{});
@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   // ---- epilogue ----
   const float lt = half_sum(l);
   // lt = 0 only for a variable-length sequence with queries but no keys (S_k = 0: no tile was visited): O = 0, LSE = -inf
-  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  // DROP: O = (1 / (1 - p)) * sum(mask o P) V / l -- the rescale is linear, so it joins the normalisation here
+  const float inv = lt > 0.f ? (DROP ? p.drop.rp : 1.0f) / lt : 0.f;
   // all waves are past the last barrier: the K/V buffers are free; wave w stages in its own 32*ROWB bytes
   store_tile_rows<D, T>(oacc, inv, smem + wave * 32 * C::ROWB, ro, qw0 * o_rs, lane, o_rs);
   if (h == 0) buf_store_f32(rl, (qw0 + r) * 4, m * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt));
