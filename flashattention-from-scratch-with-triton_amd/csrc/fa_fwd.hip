@@ -55,10 +55,10 @@ constexpr float kDeferLog2 = 6.0f;
 // Lazy running max: largest partial row sum accepted without recomputing the true max (see tile_lazy).
 constexpr float kLazySumMax = 8192.0f;
 
-// DROP: attention dropout (fa_common.h `Dropout`): P is masked and rescaled before P @ V, l keeps summing the
-// undropped p (the softmax normalisation is not affected by dropout); every tile takes the exact path.
+// DROP: attention dropout (fa_common.h `Dropout`): P is masked before P @ V (exact and lazy tiles alike), l keeps summing
+// the undropped p (the softmax normalisation is not affected by dropout), 1 / (1 - p) joins the normalisation of O.
 template <int D, typename T, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_fwd_kernel(FwdParams p) {
+__global__ __launch_bounds__(256, (D == 64 ? FA_FWD_OCC : 2)) void fa_fwd_kernel(FwdParams p) {
   using C = FwdCfg<D>;
   using vec8 = typename T::vec8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -194,6 +194,27 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   // One 64-key tile for this wave.  MASKED = false: every key visible to every row.
   // BUF = 0/1: LDS buffer known at compile time (offsets fold into the ds_read immediates);
   // BUF = -1: taken from t at run time (the few masked tiles).
+  // DROP: zero the dropped weights of one 32 x 32 block.  Registers 4g..4g+3 of a lane are four consecutive keys of its row =
+  // the four bytes of word (row & 3) of patch g, which lane g of the quad generated (fa_common.h quad_bcast).  The factor
+  // 1 / (1 - p) of the kept weights is linear in O and applied once, with the normalisation in the epilogue.
+  auto drop_weights = [&](f32x16& w16, const u32x4& mine) __attribute__((always_inline)) {
+    const unsigned thresh = p.drop.thresh;
+    const int qsel = (qw0 + r) & 3;
+    auto apply = [&](auto g_tag) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_tag)::value;
+      const unsigned w = select_word(quad_bcast4<g>(mine), qsel);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool keep = ((w >> (8 * j)) & 255u) >= thresh;
+        w16[4 * g + j] = keep ? w16[4 * g + j] : 0.f;
+      }
+    };
+    apply(std::integral_constant<int, 0>{});
+    apply(std::integral_constant<int, 1>{});
+    apply(std::integral_constant<int, 2>{});
+    apply(std::integral_constant<int, 3>{});
+  };
+
   auto tile = [&](int t, auto buf_tag, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr int BUF = decltype(buf_tag)::value;
@@ -282,26 +303,10 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
         ls[i & 3] += pe;
       }
     l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
-    if constexpr (DROP) {  // keep / drop each weight; kept ones are scaled by 1 / (1 - p)
-      const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
-      const int qrow = qw0 + r;
+    if constexpr (DROP) {  // keep / drop each weight (the row sum above is the undropped one)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (MASKED && !use[b]) continue;
-        auto apply = [&](auto g_tag) __attribute__((always_inline)) {
-          constexpr int g = decltype(g_tag)::value;
-          const unsigned w = select_word(quad_bcast4<g>(mine[b]), qrow & 3);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool keep = ((w >> (8 * j)) & 255u) >= dr.thresh;
-            sacc[b][4 * g + j] = keep ? sacc[b][4 * g + j] : 0.f;   // (the factor 1 / (1 - p) is applied once, to O)
-          }
-        };
-        apply(std::integral_constant<int, 0>{});
-        apply(std::integral_constant<int, 1>{});
-        apply(std::integral_constant<int, 2>{});
-        apply(std::integral_constant<int, 3>{});
-      }
+      for (int b = 0; b < 2; ++b)
+        if (!(MASKED && !use[b])) drop_weights(sacc[b], mine[b]);
     }
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -345,6 +350,13 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
       if (!use[0] && !use[1]) return true;  // nothing of this tile is visible to the wave
     }
     f32x16 sacc[2];
+    u32x4 mine[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if constexpr (DROP) {  // as in tile(): one Philox call per lane and key block, issued ahead of the MFMA chains
+      const Dropout dr{p.drop.thresh, p.drop.seed_lo, p.drop.seed_hi, p.drop.offset, p.drop.rp};
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (!(MASKED && !use[b])) mine[b] = dropout_patch(dr, (qw0 + r) >> 2, ((s0 + 32 * b + 4 * h) >> 2) + 2 * (r & 3), b_ * p.H + h_);
+    }
     FA_PRIO_MFMA(1);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -383,6 +395,11 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
       return false;
     }
     l += lsum;
+    if constexpr (DROP) {  // the row sum above is the undropped one; drop before P @ V
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (!(MASKED && !use[b])) drop_weights(sacc[b], mine[b]);
+    }
     FA_PRIO_VALU(0);
     FA_PRIO_MFMA(1);
 #pragma unroll
@@ -417,18 +434,6 @@ __global__ __launch_bounds__(256, (D == 64 && !DROP ? FA_FWD_OCC : 2)) void fa_f
   // merge control flow get their accumulators copied at every join.
   int t = 0;
   bool prefetched = false;
-  if constexpr (DROP) {  // the lazy path commits P before the mask could be applied consistently: exact tiles only
-    for (; t < nfull; ++t) {
-      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-      tile(t, BR{}, std::false_type{});
-      tile_sync();
-    }
-    for (; t < ntiles; ++t) {
-      if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-      tile(t, BR{}, std::true_type{});
-      tile_sync();
-    }
-  }
   while (t < nfull) {
     if (!prefetched && t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
     tile(t, BR{}, std::false_type{});
