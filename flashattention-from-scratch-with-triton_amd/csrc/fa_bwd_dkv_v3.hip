@@ -64,6 +64,13 @@ struct Dkv3Cfg {
 constexpr int kDkv3DmaIter[8] = FA_DKV3_DMA_ITERS;
 constexpr int kDkv3DmaSlot[8] = FA_DKV3_DMA_SLOTS;
 // pieces issued together (one M0 write, consecutive immediates): group k = pieces [k G, k G + G) takes piece k G's place
+// FA_DKV3_SPLIT_COMMIT (A/B hook, OFF): publish the row constants four slots before the barrier and wait with lgkmcnt(8)
+// instead of lgkmcnt(0).  +0.5-0.8 % -- but the eight reads it leaves in flight across the barrier are the transposed Q
+// fragments of THIS tile's buffer, which the other waves' DMA pieces start to overwrite five slots later: safe only by
+// timing (the hazard fa_fwd.hip's tile_sync documents), so the product drains them.
+#ifndef FA_DKV3_SPLIT_COMMIT
+#define FA_DKV3_SPLIT_COMMIT 0
+#endif
 #ifndef FA_DKV3_DMA_GROUP
 #define FA_DKV3_DMA_GROUP 2   // A/B at the headline: 2 per group +0.7 % (non-causal) / +1.2 % (causal) over single pieces, 4 the same
 #endif
@@ -93,6 +100,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
   unsigned long long seg[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = 0, nblk_ = 0;
+#ifdef FA_STAMPS_SLOTS
+  unsigned long long slot_seg[3][16] = {}, slot_last_ = 0;
+#endif
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FA_LDS char* smem = (FA_LDS char*)smem_raw;
@@ -191,8 +201,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       for (int j = 0; j < 8; ++j) dma_piece(t, buf, j);
       fetch_rc(t);
     };
-    // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet
-    auto commit_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
+    // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet.
+    // In the steady state the two halves sit four slots apart (FA_DKV3_SPLIT_COMMIT): LDS operations complete in order, so
+    // by the time at most the 8 transposed-fragment reads issued in between are still outstanding the ds_write has
+    // completed -- lgkmcnt(8) instead of draining every read in flight with lgkmcnt(0) in front of the barrier.
+    auto publish_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
       asm volatile("" ::: "memory");
 #ifndef FA_DKV3_NO_VMWAIT   // (timing ablations only: results are wrong without the wait / the barrier)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -203,6 +216,19 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         const float lse_c = (t * C::BQ + rc_row_now() < Sq) ? -rc * kLog2e : -INFINITY;
         rcp[tid] = rc_lse ? lse_c : -rc;  // rcp[row] = -LSE*log2e, rcp[BQ + row] = -delta
       }
+      asm volatile("" ::: "memory");
+    };
+    auto meet = [&](auto later_reads_tag) __attribute__((always_inline)) {
+      asm volatile("" ::: "memory");
+      constexpr int K = decltype(later_reads_tag)::value;   // LDS operations issued after the publishing ds_write
+      __builtin_amdgcn_s_waitcnt(0xC07F | (K << 8));        // lgkmcnt(K)
+#ifndef FA_DKV3_NO_BARRIER
+      __builtin_amdgcn_s_barrier();
+#endif
+      asm volatile("" ::: "memory");
+    };
+    auto commit_tile = [&](int t, int buf, bool fetched) __attribute__((always_inline)) {
+      publish_tile(t, buf, fetched);
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the ds_write above and every LDS read issued so far
 #ifndef FA_DKV3_NO_BARRIER
       __builtin_amdgcn_s_barrier();
@@ -401,6 +427,17 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         if (g == 1 && s == 1 && FOLD) keep_live(NL[0]);
         if (g == 1 && s == 5) keep_live(ND);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef FA_STAMPS_SLOTS   // (with -DFA_STAMPS: where inside the iterations next to the tile boundary the cycles go)
+        if (I == 0 || I == C::NI - 1 || I == 3) {
+          unsigned long long now_;
+          asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+          slot_seg[I == 0 ? 0 : (I == 3 ? 2 : 1)][s] += now_ - slot_last_;
+          slot_last_ = now_;
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (s == 15) {
+          asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(slot_last_)::"memory");
+        }
+#endif
       }
 #ifdef FA_STAMPS
       FA3_STAMP(I);   // seg[0..7]: block iteration I of a tile (iteration 7 without its commit)
@@ -427,9 +464,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       const FA_LDS char* qt = smem + buf * C::TILE_BYTES;
       const FA_LDS char* dt = smem + C::DO_BASE + buf * C::TILE_BYTES;
       const FA_LDS char* rct = smem + C::ROWC_OFF + buf * C::ROWC_BYTES;
-      const FA_LDS char* qn = smem + (buf ^ 1) * C::TILE_BYTES;
-      const FA_LDS char* dn = smem + C::DO_BASE + (buf ^ 1) * C::TILE_BYTES;
-      const FA_LDS char* rcn = smem + C::ROWC_OFF + (buf ^ 1) * C::ROWC_BYTES;
+      const int nb = buf ^ 1;
+      const FA_LDS char* qn = smem + nb * C::TILE_BYTES;
+      const FA_LDS char* dn = smem + C::DO_BASE + nb * C::TILE_BYTES;
+      const FA_LDS char* rcn = smem + C::ROWC_OFF + nb * C::ROWC_BYTES;
       // No branch anywhere in a tile step: hipcc sinks instructions across a conditional branch into the block that uses
       // their results (the exps of the slots before the branch then run in one burst behind it), which sched_barrier
       // cannot prevent.  Past the last tile the fetches are simply out of range: the buffer descriptors return / write
@@ -438,9 +476,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       fetch_rc(t + 1);
       auto hook = [&](int I, int s, int phase) __attribute__((always_inline)) {
         if (phase == 0) {
+#if FA_DKV3_SPLIT_COMMIT
+          if (I == C::NI - 1 && s == 0) publish_tile(t + 1, nb, true);
+#endif
           if (I == C::NI - 1 && s == 4) {   // every read of this tile's buffers is issued: hand the other buffer over
             FA3_STAMP(7);
-            commit_tile(t + 1, buf ^ 1, true);
+#if FA_DKV3_SPLIT_COMMIT
+            meet(std::integral_constant<int, 8>{});   // slots 0-3 of this iteration: 4 x 2 ds_read_b64_tr_b16 since the publish
+#else
+            commit_tile(t + 1, nb, true);
+#endif
             FA3_STAMP(8);   // seg[8]: the commit (vmcnt(0), row constants, lgkmcnt(0), barrier)
           }
           return;
@@ -449,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         for (int j = 0; j < 8; ++j)
           if (kDkv3DmaIter[j] == I && kDkv3DmaSlot[j] == s) {
             if (I == C::NI - 1) dma_piece(t + 2, buf, j);   // after this tile's commit: its own buffer is free
-            else dma_piece(t + 1, buf ^ 1, j);
+            else dma_piece(t + 1, nb, j);
           }
       };
       block_iter(std::integral_constant<int, 0>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
@@ -498,6 +543,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_)::"memory");
     d[14] = clk1_ - clk0_;
     d[15] = rt1_ - rt0_;
+#ifdef FA_STAMPS_SLOTS   // a second table behind the first (tools/stamps_dkv3.py --slots)
+    unsigned long long* e = (unsigned long long*)p.dbg + (size_t)gridDim.x * 4 * 16 + ((size_t)blockIdx.x * 4 + wave) * 48;
+    for (int i = 0; i < 48; ++i) e[i] = slot_seg[i / 16][i % 16];
+#endif
   }
 #endif
 }

@@ -75,8 +75,29 @@ template <> struct Fwd4Limit<FP16> { static constexpr float value = 32768.0f; };
 // fa_debug_fwd4_redo_count(); the increment sits on the cold path)
 __device__ unsigned g_fwd4_redo = 0;
 
+// -DFA_STAMPS (diagnostic build, tools/stamps_fwd4.py): per-phase cycle account of a wave, written to FwdParams::dbg
+#ifdef FA_STAMPS
+#define FA4_STAMP(slot)                                                           \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long now_;                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += now_ - last_;                                                    \
+    last_ = now_;                                                                 \
+  } while (0)
+#else
+#define FA4_STAMP(slot) do {} while (0)
+#endif
+
 template <int D, typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
+#ifdef FA_STAMPS
+  unsigned long long clk0_, rt0_;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = clk0_, ntile_ = 0, npass_ = 0;
+#endif
   using C = Fwd4Cfg<D>;
   using vec8 = typename T::vec8;
   constexpr bool FOLD = T::kFoldScale;
@@ -186,7 +207,14 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
     // tile t + 1 has landed for every wave, and every wave is past its reads of tile t - 1
     auto commit = [&]() __attribute__((always_inline)) {
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0x0070 | (C::INFLIGHT & 15) | ((C::INFLIGHT >> 4) << 14));   // vmcnt(INFLIGHT) lgkmcnt(0)
+      // vmcnt(INFLIGHT) only.  No LDS wait: the slot the barrier hands over to the DMA held tile t - 1, whose last reads
+      // (the V fragments of its last key block, first iteration of tile t) fed MFMAs a whole tile ago, and draining the
+      // K / V fragment reads in flight (lgkmcnt(0)) would stall the pipeline once per tile for nothing.
+#ifdef FA_FWD4_COMMIT_LGKM0   // A/B hook: the conservative form
+      __builtin_amdgcn_s_waitcnt(0x0070 | (C::INFLIGHT & 15) | ((C::INFLIGHT >> 4) << 14));
+#else
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (C::INFLIGHT & 15) | ((C::INFLIGHT >> 4) << 14));
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
@@ -424,6 +452,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 
+      FA4_STAMP(0);   // seg[0]: pass prologue -- Q fragments, ring primed, tile 0 landed (first barrier)
       float mx[2] = {-INFINITY, -INFINITY};
       if (attempt == 0) {
         // (bf16 could do without any row constant -- P = exp2(score) has the exponent range of fp32 -- and it was measured:
@@ -457,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         asm volatile("" ::: "memory");
       }
 
+      FA4_STAMP(1);   // seg[1]: scout block + row constants
       // ---- pipeline fill: a neutral "previous key block" (P = 0), the first K fragments ----
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
@@ -486,12 +516,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       for (int pp = 0; pp < 2 * C::DB; ++pp) VF[pp] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
       __builtin_amdgcn_sched_barrier(0);
 
+      FA4_STAMP(2);   // seg[2]: pipeline fill
       int t = 0, rt = 0;
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
       for (; t < nplain; ++t, rt = rt + 1 == C::NBUF ? 0 : rt + 1) tile_step(t, rt, I0{}, I0{});
+#ifdef FA_STAMPS
+      FA4_STAMP(3);   // seg[3]: the plain tiles
+      ntile_ += nplain;
+      ++npass_;
+#endif
       // The tiles level with the query tile (causal) and / or the ragged last tile.  A tile wholly inside S_k that lies in
       // the first half of the 256 keys level with the query tile masks row block 0 only (mode 2), one in the second half
       // has no row block 0 at all (mode 3); anything else masks both row blocks element-wise (mode 1).
@@ -514,14 +550,17 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
           tile_step(t + 2, nxt(nxt(rt)), I3{}, I1{});
           tile_step(t + 3, nxt(nxt(nxt(rt))), I3{}, I2{});
         }
+        FA4_STAMP(4);   // seg[4]: the masked tiles
         drain(I0{}, I2{}, ntiles - 1);
       } else {
         // a ragged last tile masks both row blocks element-wise (a tile treats its predecessor as masked too: a plain
         // predecessor carries the neutral threshold)
         for (; t < ntiles; ++t, rt = nxt(rt)) tile_step(t, rt, I1{}, I1{});
         // the set of the last block: NKB is even, so it is always set 1 -> the drain's "previous" set is 1
+        FA4_STAMP(4);
         drain(I0{}, I1{}, ntiles - 1);
       }
+      FA4_STAMP(5);   // seg[5]: drain
 
       // ---- end-of-pass check: every row sum finite and below the limit, for the whole workgroup ----
       float lt[2];
@@ -536,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       __builtin_amdgcn_s_waitcnt(0x0070);   // every DMA of the pass retired (the ring is reused below), the flag written
       __syncthreads();
       const int redo = __builtin_amdgcn_readfirstlane(*flag);
+      FA4_STAMP(6);   // seg[6]: end-of-pass check (row sums, flag, barrier with every DMA retired)
       if (!redo) {
         if (pass + 1 < npass) {   // the next pass streams the same K/V tiles: on their way during this epilogue
 #pragma unroll
@@ -552,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
           if (h == 0)
             buf_store_f32(rl, (qrow(rb) + r) * 4, mrow[rb] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt[rb]));
         }
+        FA4_STAMP(7);   // seg[7]: epilogue (and the next pass's ring priming)
         break;
       }
       __syncthreads();
@@ -561,6 +602,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       }
     }  // attempt
   }  // pass
+#ifdef FA_STAMPS
+  if (p.dbg && lane == 0) {
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 16;
+    for (int i = 0; i < 8; ++i) d[i] = seg[i];
+    d[12] = npass_;
+    d[13] = ntile_;
+    unsigned long long clk1_, rt1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_)::"memory");
+    d[14] = clk1_ - clk0_;
+    d[15] = rt1_ - rt0_;
+  }
+#endif
 }
 
 template <int D, typename T, bool CAUSAL>

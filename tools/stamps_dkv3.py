@@ -26,7 +26,7 @@ lib.fa_fwd(P(Q), P(K), P(V), P(O), P(LSE), B, H, S, S, D, 1, c, sc, st)
 lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, 1, c, sc, st)
 nkt = S // 256
 nwg = (nkt // 2 if causal else nkt) * B * H
-dbg = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nwg * 4 * 64, dtype=torch.int64, device="cuda")   # 16 per wave + 48 per wave of --slots builds
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(12):
     lib.fa_debug_set_buffer(dbg.data_ptr())
@@ -35,7 +35,8 @@ for i in range(12):
     if i == 11: e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-d = dbg.cpu().view(nwg, 4, 16).double()
+d = dbg.cpu()[:nwg * 64].view(nwg, 4, 16).double()
+slots = dbg.cpu()[nwg * 64:].view(nwg, 4, 3, 16).double()
 names = ["iteration %d (qb %d, group %d)" % (i, i >> 1, i & 1) for i in range(8)] + \
         ["commit: vmcnt(0) + row constants + barrier (per tile)", "prologue + diagonal tiles (per pass)", "pipeline fill (per pass)",
          "pipeline drain (per pass)", "epilogue (per pass)"]
@@ -50,3 +51,7 @@ for i, n in enumerate(names):
 print("per-wave share of the commit segment:", [round(float(d[:, w, 8].sum() / d[:, :, 8].sum()), 3) for w in range(4)])
 print("whole-wave: s_memtime %.0f cycles, s_memrealtime %.0f (100 MHz) => shader clock %.3f GHz; stamped share of wave lifetime %.3f"
       % (d[:, :, 14].mean(), d[:, :, 15].mean(), 0.1 * d[:, :, 14].sum() / d[:, :, 15].sum(), d[:, :, :13].sum() / d[:, :, 14].sum()))
+if slots.sum() > 0:   # -DFA_STAMPS_SLOTS build: cycles per slot (incl. ~30 for the stamp) in iterations 0, 7 and 3
+    per = slots.sum(dim=(0, 1)) / (d[:, :, 13].sum() / 8)
+    for k, nm in enumerate(("iteration 0", "iteration 7", "iteration 3")):
+        print("  %s per slot:" % nm, " ".join("%4.0f" % x for x in per[k]))
