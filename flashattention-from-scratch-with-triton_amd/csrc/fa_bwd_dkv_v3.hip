@@ -35,9 +35,15 @@
 
 namespace fa {
 
+// query rows per Q / dO tile (A/B hook: 128 or 256).  One commit (barrier, row constants, buffer hand-over) per tile; 256
+// halves their number, doubles the LDS to 132 KiB -- and measured +0.7 % non-causal / -0.7 % causal (bit-identical): the
+// cycles the stamps show next to a tile boundary do not go away with the boundary.  128 stays.
+#ifndef FA_DKV3_BQ
+#define FA_DKV3_BQ 128
+#endif
 struct Dkv3Cfg {
   static constexpr int D = 64;
-  static constexpr int BK = 256, BQ = 128, NT = 256, NW = 4;
+  static constexpr int BK = 256, BQ = FA_DKV3_BQ, NT = 256, NW = 4;
   static constexpr int QB = BQ / 32;                       // 32-row query blocks per tile
   static constexpr int NI = 2 * QB;                        // block iterations per tile (query block x key group)
   static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 16, DB = D / 32;
@@ -49,20 +55,16 @@ struct Dkv3Cfg {
   static constexpr int LDS_BYTES = 2 * NBUF * TILE_BYTES + NBUF * ROWC_BYTES;  // 66 KiB
   static constexpr int DMA_PER_MAT = TILE_BYTES / (NW * 1024);                 // 4 pieces of Q and 4 of dO per wave
   static constexpr int RPI = 1024 / ROWB;                  // tile rows per 1-KiB DMA piece
+  static constexpr int NP = 2 * DMA_PER_MAT;               // pieces per wave and tile: [0, DMA_PER_MAT) Q, then dO
+  static constexpr int RCN = 2 * BQ / NT;                  // row constants (LSE and delta rows of a tile) loaded per thread
+  static_assert(BQ == 128 || BQ == 256, "one or two row constants per thread");
 };
 
-// where the 8 LDS-DMA pieces of a coming tile (0-3 Q, 4-7 dO rows of this wave's 32-row share) are issued: block
-// iteration and slot.  The commit inside iteration 7 of tile t frees tile t's own buffer, so a piece placed in iteration 7
-// (slot >= 5) already belongs to tile t + 2; pieces in iterations 0-6 of tile t + 1 complete that tile.  Everything
-// is waited for by the next commit (vmcnt(0)), a whole tile time after the first piece.  A/B hooks: -DFA_DKV3_DMA_ITERS / _SLOTS.
-#ifndef FA_DKV3_DMA_ITERS
-#define FA_DKV3_DMA_ITERS {7, 7, 7, 7, 0, 0, 0, 0}
-#endif
-#ifndef FA_DKV3_DMA_SLOTS
-#define FA_DKV3_DMA_SLOTS {9, 11, 13, 15, 9, 11, 13, 15}
-#endif
-constexpr int kDkv3DmaIter[8] = FA_DKV3_DMA_ITERS;
-constexpr int kDkv3DmaSlot[8] = FA_DKV3_DMA_SLOTS;
+// where the LDS-DMA pieces of a coming tile (first the Q rows, then the dO rows of this wave's share) are issued: block
+// iteration and slot.  The commit inside the last iteration of tile t frees tile t's own buffer, so a piece placed in that
+// iteration (slot >= 5) already belongs to tile t + 2; pieces in the earlier iterations of tile t + 1 complete that tile.
+// Everything is waited for by the next commit (vmcnt(0)), most of a tile time after the first piece.
+// (group k = pieces [k G, k G + G): groups 0-1 in the last iteration, slots 9 and 13, then two per iteration from 0 on)
 // pieces issued together (one M0 write, consecutive immediates): group k = pieces [k G, k G + G) takes piece k G's place
 // FA_DKV3_SPLIT_COMMIT (A/B hook, OFF): publish the row constants four slots before the barrier and wait with lgkmcnt(8)
 // instead of lgkmcnt(0).  +0.5-0.8 % -- but the eight reads it leaves in flight across the barrier are the transposed Q
@@ -75,6 +77,8 @@ constexpr int kDkv3DmaSlot[8] = FA_DKV3_DMA_SLOTS;
 #define FA_DKV3_DMA_GROUP 2   // A/B at the headline: 2 per group +0.7 % (non-causal) / +1.2 % (causal) over single pieces, 4 the same
 #endif
 constexpr int kDkv3DmaGroup = FA_DKV3_DMA_GROUP;
+constexpr int dkv3_dma_iter(int j) { return j / kDkv3DmaGroup < 2 ? Dkv3Cfg::NI - 1 : (j / kDkv3DmaGroup - 2) / 2; }
+constexpr int dkv3_dma_slot(int j) { return 9 + 4 * ((j / kDkv3DmaGroup) & 1); }
 
 #ifdef FA_STAMPS
 #define FA3_STAMP(slot)                                                           \
@@ -141,8 +145,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
   const long long rowc_off = b_ * p.lse_sb + h_ * p.lse_sh + si.q0;
   // row constants of a query tile: waves 0-1 load its LSE rows, waves 2-3 its delta rows, through ONE wave-uniform
   // descriptor and an unconditional load (fa_bwd_dkv_v2.hip: a divergent `if` around it costs a hidden vmcnt(0))
+  // (BQ = 256: every thread loads one LSE row and one delta row -- two descriptors, still no divergence)
   const bool rc_lse = wave < C::BQ / 64;
   const __amdgpu_buffer_rsrc_t rrc = make_rsrc((rc_lse ? p.lse : p.delta) + rowc_off, (unsigned)Sq * 4);
+  const __amdgpu_buffer_rsrc_t rrc_d = make_rsrc(p.delta + rowc_off, (unsigned)Sq * 4);
   auto rc_row_now = [&]() __attribute__((always_inline)) -> int {
     int x;
     asm volatile("v_and_b32 %0, %1, %2" : "=v"(x) : "n"(C::BQ - 1), "v"(tid));
@@ -187,18 +193,21 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
     const int t_diag_end = CAUSAL ? min(ntiles, t_start + C::BK / C::BQ + 1) : 0;  // tiles run with the causal mask
 
     // ---- DMA of one Q/dO tile + the row-constant load (one float per thread) ----
-    float rc = 0.f;
+    float rc = 0.f, rc_d = 0.f;
     auto dma_piece = [&](int t, int buf, int j) __attribute__((always_inline)) {  // j: 0-3 Q, 4-7 dO; the group led by j
       if (j % kDkv3DmaGroup != 0) return;
-      const int i = j & 3;
+      const int i = j % C::DMA_PER_MAT;
       const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * i) * C::ROWB;
-      if (j < 4) dma_pieces<kDkv3DmaGroup>(rq, lds_addr_of(smem + dst), dma_q + i, t * C::BQ * q_rs);
+      if (j < C::DMA_PER_MAT) dma_pieces<kDkv3DmaGroup>(rq, lds_addr_of(smem + dst), dma_q + i, t * C::BQ * q_rs);
       else dma_pieces<kDkv3DmaGroup>(rdo, lds_addr_of(smem + C::DO_BASE + dst), dma_do + i, t * C::BQ * do_rs);
     };
-    auto fetch_rc = [&](int t) __attribute__((always_inline)) { rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4); };
+    auto fetch_rc = [&](int t) __attribute__((always_inline)) {
+      rc = buf_load_f32(rrc, (t * C::BQ + rc_row_now()) * 4);
+      if constexpr (C::RCN == 2) rc_d = buf_load_f32(rrc_d, (t * C::BQ + rc_row_now()) * 4);
+    };
     auto fetch_tile = [&](int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dma_piece(t, buf, j);
+      for (int j = 0; j < C::NP; ++j) dma_piece(t, buf, j);
       fetch_rc(t);
     };
     // everything of the fetched tile has landed (vmcnt(0)): publish the scaled row constants, then meet.
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
         // rows past S_q must give P = 0 (K:355-356): exp2(-inf) = 0
         const float lse_c = (t * C::BQ + rc_row_now() < Sq) ? -rc * kLog2e : -INFINITY;
         rcp[tid] = rc_lse ? lse_c : -rc;  // rcp[row] = -LSE*log2e, rcp[BQ + row] = -delta
+        if constexpr (C::RCN == 2) rcp[C::BQ + tid] = -rc_d;
       }
       asm volatile("" ::: "memory");
     };
@@ -292,8 +302,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
     auto pipe_fill = [&](int t, int buf) __attribute__((always_inline)) {
       // the pieces a previous tile step would have issued in its iteration 7 (nothing of tile t + 1 is in flight yet)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (kDkv3DmaIter[j] == C::NI - 1) dma_piece(t + 1, buf ^ 1, j);
+      for (int j = 0; j < C::NP; ++j)
+        if (dkv3_dma_iter(j) == C::NI - 1) dma_piece(t + 1, buf ^ 1, j);
       const FA_LDS char* qt = smem + buf * C::TILE_BYTES;
       const FA_LDS char* dt = smem + C::DO_BASE + buf * C::TILE_BYTES;
       const FA_LDS char* rcp = smem + C::ROWC_OFF + buf * C::ROWC_BYTES;
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
 #endif
       }
 #ifdef FA_STAMPS
-      FA3_STAMP(I);   // seg[0..7]: block iteration I of a tile (iteration 7 without its commit)
+      FA3_STAMP(I * 8 / C::NI);   // seg[0..7]: block iteration I of a tile (pairs of iterations at 16 per tile; the last without its commit)
       ++nblk_;
 #endif
     };
@@ -491,8 +501,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
           return;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (kDkv3DmaIter[j] == I && kDkv3DmaSlot[j] == s) {
+        for (int j = 0; j < C::NP; ++j)
+          if (dkv3_dma_iter(j) == I && dkv3_dma_slot(j) == s) {
             if (I == C::NI - 1) dma_piece(t + 2, buf, j);   // after this tile's commit: its own buffer is free
             else dma_piece(t + 1, nb, j);
           }
@@ -505,6 +515,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       block_iter(std::integral_constant<int, 5>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
       block_iter(std::integral_constant<int, 6>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
       block_iter(std::integral_constant<int, 7>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      if constexpr (C::NI == 16) {
+        block_iter(std::integral_constant<int, 8>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 9>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 10>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 11>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 12>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 13>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 14>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+        block_iter(std::integral_constant<int, 15>{}, mask_tag, t * C::BQ, qt, dt, rct, qn, dn, rcn, hook);
+      }
     };
 
 #ifdef FA_STAMPS
