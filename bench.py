@@ -84,6 +84,10 @@ def parse_args(argv=None):
     ap.add_argument("--layout", default="bhsd", choices=["bhsd", "bshd"],
                     help="bhsd: contiguous [B,H,S,D] inputs (the BASELINE config); bshd: Q/K/V are transposed views of "
                          "[B,S,H,D] buffers, read in place by the kernels (the reference would copy them)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="run the N-rank code path with every rank on GPU 0 and gloo as the process group (RCCL refuses two "
+                         "ranks on one device): the real kernels, shards, barriers, max-over-ranks and the JSON line of a "
+                         "multi-GPU run on a one-GPU box; the line carries \"rehearsal\": true and is not a measurement")
     ap.add_argument("--harness-selftest", action="store_true",
                     help="CPU / gloo: exercise the rank spawn, sharding, barrier and reduce plumbing with a trivial "
                          "torch op as the step; no GPU, no kernels, value = null (tests/test_dist.py)")
@@ -260,11 +264,15 @@ def run_rank(args):
     if args.harness_selftest:
         return harness_selftest(args)
     ndev = torch.cuda.device_count()
-    if ndev < world:
+    if ndev < world and not args.rehearse_one_gpu:
         fail("%d ranks requested but only %d GPU(s) visible" % (world, ndev))
     if not torch.cuda.is_available():
         fail("bench.py needs a GPU (the HIP path is the only path)")
-    rank, local_rank, world = sc.init()
+    if args.rehearse_one_gpu:
+        rank, local_rank, world = sc.init(backend="gloo")
+        local_rank = 0
+    else:
+        rank, local_rank, world = sc.init()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import My_FlashAttention_optimized as M  # raises if libmi355fa.so is missing
@@ -355,6 +363,8 @@ def run_rank(args):
             "checksum": m["checksum"],
             "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu, "config5": c5,
         }
+        if args.rehearse_one_gpu:
+            line["rehearsal"] = True   # every rank shared GPU 0: plumbing check, not a measurement
         if "ms_fwd_copy" in m:
             line["fwd_ms_if_views_were_copied_first"] = round(m["ms_fwd_copy"], 4)
         print(json.dumps(line), flush=True)

@@ -1,4 +1,4 @@
-"""CPU tests (gloo, world_size 2) of the batch-sharding harness used by bench.py for N > 1."""
+"""CPU tests (gloo, world_size 2) of the batch-sharding harness used by bench.py for N > 1, and one GPU rehearsal of that path."""
 import os
 import socket
 import sys
@@ -159,3 +159,32 @@ def test_bench_metric_string_follows_the_arguments():
     assert (a.gpus, a.config) == (1, "3") and a.steps * 1.3 < 60          # the default finishes within minutes
     assert bench.flops_fwd(64, 32, 8192, 8192, 64, True) * 3.5 == 61572651155456     # tests/golden/kat.json
     assert len(bench.kernel_source_hash()) == 16
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_code_path_on_one_gpu_matches_the_single_rank_union():
+    """The N > 1 path of bench.py with the real kernels (no 2-GPU box on this pool): two ranks share GPU 0 over gloo
+    (--rehearse-one-gpu).  The line must describe a 2-rank weak-scaling job, and the checksum of the ranks' outputs must
+    equal that of ONE rank computing the union of their shards -- the per-batch seeding makes it independent of the
+    world size."""
+    import json
+    import subprocess
+    common = ["--heads", "2", "--seq", "512", "--steps", "2", "--warmup", "1", "--preroll-s", "0", "--no-cpu-baseline"]
+
+    def run(extra):
+        e = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            e.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=e, capture_output=True,
+                           text=True, timeout=500)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    two = run(["--gpus", "2", "--batch", "2", "--rehearse-one-gpu"])
+    one = run(["--gpus", "1", "--batch", "4"])
+    assert two["rehearsal"] is True and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["global_batch"] == 4 == one["config"]["global_batch"]
+    assert two["config"]["parallelism"] == "batch-sharded x2, no collective"
+    assert abs(two["checksum"] - one["checksum"]) <= 1e-6 * abs(one["checksum"])
+    assert two["value"] > 0 and two["ms_per_step"] > 0
