@@ -93,6 +93,55 @@ typedef __attribute__((ext_vector_type(4))) unsigned agpr4_t;   // a 128-bit fra
 FA_MFMA_ASM_(mfma_v_bf16, "v_mfma_f32_32x32x16_bf16")
 FA_MFMA_ASM_(mfma_v_f16, "v_mfma_f32_32x32x16_f16")
 #undef FA_MFMA_ASM_
+// The same three forms with the B operand PINNED to literal accumulator registers: fragment F lives in
+// a[192 + 4F : 195 + 4F], F = 0..15 (fa_bwd_dq_v4.hip: its resident Q^T / dO^T fragments, 64 registers, do not fit beside
+// everything else that must sit in architectural VGPRs -- the A and B operands of an MFMA have independent AGPR bits, C and
+// D share one, so the row constants cannot follow).  Why literal names and not an "a" operand: hipcc splits the live range
+// of such an operand where it pleases and copies it back (v_accvgpr_write) right in front of the asm statement, whose
+// MFMA then reads the register inside the write's wait states -- hipcc pads no hazard for an asm statement (seen: a wrong
+// row block in the fp16 causal kernel).  Registers hipcc never allocates cannot be copied.  What guarantees that it never
+// does: tools/mfma_lint.py (CPU test) reads the code objects and fails if anything but pin_write() writes a[192:255]
+// or anything but an MFMA reads them.
+constexpr int kPinBase = 192;
+FA_DEVINL void pin_reserve() { asm volatile("" ::: "a192", "a255"); }   // the kernel descriptor allocates the whole AGPR file
+template <int F>
+FA_DEVINL void pin_write(u32x4 v) {
+  static_assert(F >= 0 && F < 16, "16 pinned fragments");
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\t"
+               "v_accvgpr_write_b32 a[%c7], %3"
+               :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 1),
+                  "i"(kPinBase + 4 * F + 2), "i"(kPinBase + 4 * F + 3));
+}
+template <int F>
+FA_DEVINL u32x4 pin_read() {
+  u32x4 v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\t"
+               "v_accvgpr_read_b32 %3, a[%c7]"
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
+               : "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 1), "i"(kPinBase + 4 * F + 2), "i"(kPinBase + 4 * F + 3));
+  return v;
+}
+#define FA_MFMA_ASM_PIN_(NAME, OP)                                                                                  \
+  template <int F> FA_DEVINL void NAME##_first(f32x16& d, u32x4 a, const f32x16& c) {                              \
+    asm volatile(OP " %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3)); \
+  }                                                                                                                \
+  template <int F> FA_DEVINL void NAME##_first0(f32x16& d, u32x4 a) {                                              \
+    asm volatile(OP " %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3)); \
+  }                                                                                                                \
+  template <int F> FA_DEVINL void NAME##_acc(f32x16& d, u32x4 a) {                                                 \
+    asm volatile(OP " %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3)); \
+  }
+FA_MFMA_ASM_PIN_(mfma_vp_bf16, "v_mfma_f32_32x32x16_bf16")
+FA_MFMA_ASM_PIN_(mfma_vp_f16, "v_mfma_f32_32x32x16_f16")
+#undef FA_MFMA_ASM_PIN_
+struct MfmaPin {   // T-dispatch of the forms above
+  template <int F> static FA_DEVINL void first(BF16*, f32x16& d, u32x4 a, const f32x16& c) { mfma_vp_bf16_first<F>(d, a, c); }
+  template <int F> static FA_DEVINL void first0(BF16*, f32x16& d, u32x4 a) { mfma_vp_bf16_first0<F>(d, a); }
+  template <int F> static FA_DEVINL void acc(BF16*, f32x16& d, u32x4 a) { mfma_vp_bf16_acc<F>(d, a); }
+  template <int F> static FA_DEVINL void first(FP16*, f32x16& d, u32x4 a, const f32x16& c) { mfma_vp_f16_first<F>(d, a, c); }
+  template <int F> static FA_DEVINL void first0(FP16*, f32x16& d, u32x4 a) { mfma_vp_f16_first0<F>(d, a); }
+  template <int F> static FA_DEVINL void acc(FP16*, f32x16& d, u32x4 a) { mfma_vp_f16_acc<F>(d, a); }
+};
 template <typename A4> FA_DEVINL void BF16::mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c) { mfma_v_bf16_first(d, a, b, c); }
 template <typename A4> FA_DEVINL void BF16::mfma_v_first0(f32x16& d, u32x4 a, A4 b) { mfma_v_bf16_first0(d, a, b); }
 template <typename A4> FA_DEVINL void BF16::mfma_v_acc(f32x16& d, u32x4 a, A4 b) { mfma_v_bf16_acc(d, a, b); }

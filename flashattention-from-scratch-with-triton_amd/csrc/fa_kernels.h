@@ -143,6 +143,8 @@ inline hipError_t opt_in_lds(const void* kern, int bytes, std::atomic<unsigned l
 //                                 row constant m fixed per pass and verified at its end (D = 64, 128; fixed length)
 //   dQ        1 = fa_bwd_dq.hip   as forward 1;  2 = fa_bwd_dq_v2.hip as forward 2;
 //             3 = fa_bwd_dq_v3.hip  128-row workgroups, per-wave three-stage software pipeline (D = 64)
+//             4 = fa_bwd_dq_v4.hip  256-row workgroups, ONE wave per SIMD with 64 rows, every K / V / K^T fragment read
+//                                   from LDS once for both row blocks, continuous hand-ordered pipeline (D = 64, fixed length)
 //   dK/dV     1 = fa_bwd_dkv.hip  128-key workgroups, 64-row Q/dO tiles;
 //             2 = fa_bwd_dkv_v2.hip  128-row Q/dO tiles, hand-ordered pipeline (D = 64, 128)
 //             3 = fa_bwd_dkv_v3.hip  256-key workgroups, ONE wave per SIMD with 64 keys, every Q / dO fragment read from
@@ -175,11 +177,15 @@ inline int pick_fwd_impl(int forced, int D, int dtype, int B, int H, int Sq, int
   if (f == 4 && (!fixed_length || (causal && !(Sk % 256 == 0 && Sk >= (Sq + 255) / 256 * 256)))) f = 1;
   return (f >= 2 && f <= 4) ? f : 1;
 }
-inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous) {
+inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool contiguous,
+                        bool fixed_length = true) {
   int f = forced ? forced : table_family(kKernelDq, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  // family 4: fixed length, whole 128-key tiles; causal launches only when every 256-row query tile has all 256 keys level
+  // with it (its diagonal phase has no ragged path: fa_bwd_dq_v4.hip); otherwise the pipelined family 3
+  if (f == 4 && (D != 64 || !fixed_length || Sk % 128 != 0 || (causal && !(Sk % 256 == 0 && Sk >= (Sq + 255) / 256 * 256)))) f = 3;
   if (f == 2 && (D != 64 || !contiguous)) f = 1;
   if (f == 3 && D != 64) f = 1;
-  return (f == 2 || f == 3) ? f : 1;
+  return (f >= 2 && f <= 4) ? f : 1;
 }
 inline int pick_dkv_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal) {
   if (D != 64 && D != 128) return 1;
