@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv3_kernel(BwdParams p) {
       constexpr bool MASK = decltype(mask_tag)::value;
       const int e = tau - 5, m = tau - 10;
       if (e >= 0 && e < 16) {
-        float x = FOLD ? X[e] : __builtin_fmaf(X[e], c2, nl[e]);
+        // the block's FIRST exp not above this slot's MFMA (fa_common.h here; hipcc pads an s_nop behind every such
+        // statement -- one per block is free, one per exp was not)
+        float x = e == 0 ? here(X[e]) : X[e];
+        if constexpr (!FOLD) x = __builtin_fmaf(x, c2, nl[e]);
         if constexpr (MASK) x = thr_b > (e & 3) + 8 * (e >> 2) ? -INFINITY : x;
         X[e] = __builtin_amdgcn_exp2f(x);
       }

@@ -152,6 +152,15 @@ template <typename A4> FA_DEVINL void FP16::mfma_v_acc(f32x16& d, u32x4 a, A4 b)
 // statement with an AMDGPU register constraint written directly in a __global__ body makes the HOST pass drop the
 // kernel's stub without a diagnostic (undefined symbol at load time).
 FA_DEVINL void keep_live(const f32x16& x) { asm volatile("" ::"v"(x)); }
+// `x` becomes a value DEFINED at this point of the chain of volatile asm statements: an instruction that consumes it cannot
+// be placed above the asm MFMA written in front of this call.  sched_barrier(0) pins the machine scheduler only -- the
+// instruction selector's own linearisation had moved the first exp of a block one MFMA slot up in fa_bwd_dkv_v3.hip, to 10
+// wait states behind the chain's last MFMA where an 8-pass MFMA's result wants 12 (tools/mfma_lint.py rule R3).
+// Not free: hipcc pads one s_nop between an asm statement and a VALU instruction that reads its output.
+FA_DEVINL float here(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 #ifdef FA_DKV3_SKEW
 #define FA_SKEW_NOPS_1 "s_nop 15\n\t"
 #define FA_SKEW_NOPS_2 "s_nop 15\n\ts_nop 15\n\t"

@@ -333,6 +333,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         // ---- VALU: the previous key block at tau = NSLOT + s, this one at tau = s ----
         block_valu(C::NSLOT + s, S_[PSET], pk[PSET], thr[PSET], PrevMask{}, std::integral_constant<bool, PREV0>{});
         block_valu(s, S_[SET], pk[SET], thr[SET], OwnMask{}, std::integral_constant<bool, OWN0>{});
+        // An MFMA reads its C operand over its passes and hipcc pads that hazard for its own MFMAs only: in the LAST block of
+        // a pass -m is dead after the chain starts (slots 0 and 1), and hipcc reused its registers for a masked exponent
+        // argument six instructions later (tools/mfma_lint.py rule R2; fa_bwd_dkv_v3.hip met the same) -- live one more slot
+        if constexpr (CHAIN_M) {
+          if (s == 1 && OWN0) keep_live(negm[0]);
+          if (s == 2) keep_live(negm[CHAIN_M ? 1 : 0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };

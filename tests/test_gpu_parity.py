@@ -297,6 +297,46 @@ def test_dkv_family3_is_bit_identical_to_family2():
                     assert torch.equal(a, b), (dtype, causal, Sq, Sk)
 
 
+def test_dq_family4_is_bit_identical_to_family3():
+    """Round 4: the one-wave-per-SIMD dQ kernel (fa_bwd_dq_v4.hip: 64 rows per wave, per-wave diagonal phase, diagonal mask in
+    the chain-start operand) keeps the maths, the rounding points and the accumulation order of family 3 -- identical dQ and
+    delta bits, causal and full, both dtypes; shapes it takes itself (whole 128-key tiles; causal: whole 256-row tiles covered
+    by S_k, one and several query tiles, paired and unpaired grids, S_q < S_k, a ragged S_q) and shapes that must fall back."""
+    import ctypes
+    import _mi355fa as fa
+    M = _host()
+    fa.lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+    pick = fa.lib.fa_debug_pick
+    pick.argtypes = [ctypes.c_int] * 8
+    took4 = 0
+    for dtype in (BF16, F16):
+        for causal in (False, True):
+            for (B, H, Sq, Sk) in ((1, 2, 256, 256), (2, 3, 768, 768), (1, 2, 256, 1024), (1, 1, 200, 512), (2, 2, 1280, 1280),
+                                   (1, 2, 1024, 128), (1, 2, 500, 500), (4, 32, 512, 512)):
+                Q, K, V, dO = (x.cuda() for x in rand_inputs(B, H, Sq, Sk, 64, dtype, seed=Sq + Sk))
+                O, LSE = M.flash_attention_forward(Q, K, V, causal)
+                got = {}
+                for fam in (3, 4):
+                    fa.lib.fa_debug_force_impl(0, fam, 0)
+                    try:
+                        took4 += fam == 4 and pick(1, 64, int(dtype == BF16), int(causal), B, H, Sq, Sk) == 4
+                        dQ = torch.full_like(Q, float("nan"))
+                        delta = torch.full_like(LSE, float("nan"))
+                        st = torch.cuda.current_stream().cuda_stream
+                        rc = fa.lib.fa_bwd_dq(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), LSE.data_ptr(),
+                                              dQ.data_ptr(), delta.data_ptr(), B, H, Sq, Sk, 64, int(dtype == BF16), int(causal),
+                                              64 ** -0.5, st)
+                        assert rc == 0, fa.lib.fa_last_error()
+                        torch.cuda.synchronize()
+                        got[fam] = (dQ, delta)
+                    finally:
+                        fa.lib.fa_debug_force_impl(0, 0, 0)
+                assert not torch.isnan(got[4][0].float()).any() and not torch.isnan(got[4][1]).any(), (dtype, causal, Sq, Sk)
+                for a, b in zip(got[3], got[4]):
+                    assert torch.equal(a, b), (dtype, causal, Sq, Sk)
+    assert took4 >= 20   # the shapes above are mostly ones family 4 really runs
+
+
 @pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
 def test_large_magnitude_scores_bf16(impl, causal):
     """Scaled-up Q and K (|s * log2e / sqrt(D)| up to ~50-100): the folded-scale bf16 kernels carry the exponent
