@@ -60,8 +60,36 @@ constexpr int dq4_exp_tau(int e) { return e < 14 ? 5 + e / 2 : 12; }
 constexpr int dq4_mul_tau(int m) { return m < 2 ? 12 : 13 + (m - 2) / 4; }
 constexpr int dq4_cvt_tau(int j) { return j == 0 ? 13 : 14 + (j - 1) / 2; }
 
+// -DFA_STAMPS (diagnostic build, tools/stamps_dq4.py): per-phase cycle account of a wave, written to BwdParams::dbg.
+// seg[0] pass prologue (ring primed, resident operands, first barrier, fill)   seg[1] unmasked tiles   seg[2] diagonal phase
+// seg[3] drain   seg[4] epilogue   seg[5..7] parts of the prologue (seg[0] is then the fill alone)   -DFA_STAMPS_ITER adds seg[8 + I] block iteration I of an unmasked tile, seg[16] the commit
+#ifdef FA_STAMPS
+#define FA4Q_STAMP(slot)                                                          \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long now_;                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += now_ - last_;                                                    \
+    last_ = now_;                                                                 \
+  } while (0)
+#else
+#define FA4Q_STAMP(slot) do {} while (0)
+#endif
+#ifdef FA_STAMPS_ITER
+#define FA4Q_ISTAMP(slot) FA4Q_STAMP(slot)
+#else
+#define FA4Q_ISTAMP(slot) do {} while (0)
+#endif
+
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
+#ifdef FA_STAMPS
+  unsigned long long clk0_, rt0_;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
+  unsigned long long seg[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = clk0_, ntile_ = 0, npass_ = 0;
+#endif
   using C = Dq4Cfg;
   using vec8 = typename T::vec8;
   constexpr int D = C::D;
@@ -71,40 +99,75 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
-  // causal: a workgroup takes the query-tile pair (nq-1-i, i) -> equal work everywhere (see fa_fwd.hip)
-  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  // Work list: one item = one 256-row query tile, or (causal, paired) the tile pair (nq-1-i, i) -> equal work per item (see
+  // fa_fwd.hip); the XCD-aware order gives every XCD a contiguous run of (batch, head) slices.  Causal launches are
+  // PERSISTENT: one workgroup per CU walks items blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8 keeps all
+  // of them on one XCD's slice list), because a pass's resident operands are fetched during the PREVIOUS pass (below) and the
+  // first pass of an item has no previous pass unless the workgroup stays.
   const bool paired = CAUSAL && p.pair;
   const int nq = p.n_tiles;
   const int per_bh = paired ? (nq + 1) / 2 : nq;
-  const int bh = w / per_bh;
-  const int idx = w - bh * per_bh;
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int n_items = per_bh * p.B * p.H;
   const int Sq = p.Sq, Sk = p.Sk;
-  const int npass = (paired && idx != nq - 1 - idx) ? 2 : 1;
-
   // Q, K, V, dO, O, dQ may be strided views with a contiguous head dim (fa_fwd.hip); no variable-length launches here
   const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs, o_rs = p.lo.rs, dq_rs = p.ldq.rs;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh, view_bytes(Sq, o_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + b_ * p.ldq.sb + h_ * p.ldq.sh, view_bytes(Sq, dq_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, view_bytes(Sk, kv_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, view_bytes(Sk, kv_rs, C::ROWB));
-  const long long rowc_off = b_ * p.lse_sb + h_ * p.lse_sh;
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + rowc_off, (unsigned)Sq * 4);
-  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + rowc_off, (unsigned)Sq * 4);
   const float c2 = p.scale * kLog2e;
   const int lds0 = (int)lds_addr_of(smem);
   pin_reserve();
 
+  struct Work {
+    int b, h, idx, npass;
+  };
+  auto decode = [&](int item) __attribute__((always_inline)) -> Work {
+    const int w = xcd_remap(item, n_items);
+    const int bh = w / per_bh, idx = w - bh * per_bh, b = bh / p.H;
+    return Work{b, bh - b * p.H, idx, (paired && idx != nq - 1 - idx) ? 2 : 1};
+  };
+  auto tile_of = [&](const Work& wk, int pass) __attribute__((always_inline)) -> int {   // heavy tile first
+    return paired ? (pass == 0 ? nq - 1 - wk.idx : wk.idx) : (CAUSAL ? nq - 1 - wk.idx : wk.idx);
+  };
+  // The resident operands of a pass -- this lane's Q, dO and O fragments of both row blocks (24 x 16 bytes) and its two LSE
+  // rows -- are requested a whole phase before the pass needs them, into the prefetch accumulator registers of fa_common.h
+  // (Q k-step ks of row block rb -> a[96 + 48 rb + 4 ks ..], dO + 16, O + 32; LSE -> a[92 + rb]).  Why: these rows are cold
+  // (nobody else reads them), every workgroup of a launch starts a pass at about the same moment, and 256 CUs asking for
+  // 96 KiB each is an HBM burst: issuing the 26 loads took a wave 8k cycles of a 75k-cycle pass (stamps, tools/stamps_dq4.py),
+  // with nothing else resident on the CU to cover them; without the traffic the kernel ran 11 % faster.  Issued from inside
+  // the previous pass they cost their issue slots only, and the HBM sees them spread over the whole launch.
+  auto prefetch = [&](const Work& wk, int pass) __attribute__((always_inline)) {
+    const int ln = lane_id_now(), r = ln & 31, h = ln >> 5;
+    const int q0 = tile_of(wk, pass) * C::BM;
+    const int row[2] = {q0 + 32 * wave + r, q0 + 32 * (7 - wave) + r};
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + wk.b * p.lq.sb + wk.h * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
+    const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + wk.b * p.ldo.sb + wk.h * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)p.o + wk.b * p.lo.sb + wk.h * p.lo.sh, view_bytes(Sq, o_rs, C::ROWB));
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + wk.b * p.lse_sb + wk.h * p.lse_sh, (unsigned)Sq * 4);
+    static_for<2 * C::KS>([&](auto i_) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_)::value, rb = i / C::KS, ks = i % C::KS, A = kPfBase + 48 * rb + 4 * ks;
+      const int col = (2 * ks + h) * 16;
+      pf_load16<A>(rq, row[rb] * q_rs + col);
+      pf_load16<A + 16>(rdo, row[rb] * do_rs + col);
+      pf_load16<A + 32>(ro, row[rb] * o_rs + col);
+    });
+    pf_load4<kPfLse>(rl, row[0] * 4);
+    pf_load4<kPfLse + 1>(rl, row[1] * 4);
+  };
+
+  int item = blockIdx.x;
+  Work wk = decode(item);
+  prefetch(wk, 0);   // the first pass of a workgroup: no previous pass to hide behind
+  for (; item < n_items; item += gridDim.x, wk = decode(min(item, n_items - 1))) {
+  const int b_ = wk.b, h_ = wk.h, npass = wk.npass;
+  const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + b_ * p.ldq.sb + h_ * p.ldq.sh, view_bytes(Sq, dq_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, view_bytes(Sk, kv_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, view_bytes(Sk, kv_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
+
   for (int pass = 0; pass < npass; ++pass) {
     // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
     const int lane = lane_id_now(), r = lane & 31, h = lane >> 5;
-    const int qt = paired ? (pass == 0 ? nq - 1 - idx : idx) : (CAUSAL ? nq - 1 - idx : idx);  // heavy first
-    const int q0_wg = qt * C::BM;
+    const int q0_wg = tile_of(wk, pass) * C::BM;
     // this wave's two 32-row blocks: {w, 7-w} of the workgroup's eight (equal causal work per wave, see the header)
     const int qrow[2] = {q0_wg + 32 * wave, q0_wg + 32 * (7 - wave)};
-    if (pass) __syncthreads();  // the previous pass staged its dQ tiles in the K ring
 
     // tiles [0, nfull) are unmasked for every row of the workgroup; causal launches add the two tiles level with the
     // query tile (the launcher guarantees that they exist: S_k is a multiple of 256 and covers every query tile)
@@ -127,14 +190,6 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       if (g4 < 2) dma_pieces<2>(rk, (unsigned)(lds0 + dst), dma_src + i, soff);
       else dma_pieces<2>(rv, (unsigned)(lds0 + C::V_BASE + dst), dma_src + i, soff);
     };
-    // The ring is primed before the resident operands are fetched (one memory latency per pass): tiles 0 and 1 whole and
-    // the part of tile 2 that a steady-state tile step issues in its last iteration (dma_at below).
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) dma_group(0, 0, g4);
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) dma_group(1, 1, g4);
-    dma_group(2, 2, 0);
-    dma_group(2, 2, 1);
 
     // ---- resident B operands: Q^T and dO^T fragments of both row blocks; delta (K:210-211, from the rounded O) ----
     // They live in the pinned accumulator registers of fa_common.h (pin_write / MfmaPin): fragment F = 8 rb + ks holds
@@ -142,21 +197,31 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     // 256 ARCHITECTURAL registers (C and D share one AGPR bit), which these 64 registers would overflow.
     float nl[2];       // -LSE * log2e of this lane's row
     f32x16 NL[FOLD ? 2 : 1], ND[2];   // the same / -delta in every register: C operands of the chain starts
+    // the ring: tiles 0 and 1 whole and the part of tile 2 that a steady-state tile step issues in its last iteration
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) dma_group(0, 0, g4);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) dma_group(1, 1, g4);
+    dma_group(2, 2, 0);
+    dma_group(2, 2, 1);
+    FA4Q_STAMP(5);   // seg[5]: ring primed (20 pieces issued)
+    // everything older than those 20 pieces has landed: the prefetch loads of this pass (and the previous pass's stores)
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     auto load_rows = [&](auto rb_tag) __attribute__((always_inline)) {
       constexpr int rb = decltype(rb_tag)::value;
       float dsum = 0.f;
       vec8 qv[C::KS], dv[C::KS];
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        const int col = (2 * ks + h) * 16;
-        qv[ks] = as_vec8<T>(buf_load16(rq, (qrow[rb] + r) * q_rs + col));
-        dv[ks] = as_vec8<T>(buf_load16(rdo, (qrow[rb] + r) * do_rs + col));
-        const vec8 ov = as_vec8<T>(buf_load16(ro, (qrow[rb] + r) * o_rs + col));
+      static_for<C::KS>([&](auto ks_) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_)::value, A = kPfBase + 48 * rb + 4 * ks;
+        qv[ks] = as_vec8<T>(acc_read4<A>());
+        dv[ks] = as_vec8<T>(acc_read4<A + 16>());
+        const vec8 ov = as_vec8<T>(acc_read4<A + 32>());
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsum = __builtin_fmaf((float)dv[ks][j], (float)ov[j], dsum);
-      }
+      });
       const float delta = half_sum(dsum);
-      nl[rb] = -buf_load_f32(rl, (qrow[rb] + r) * 4) * kLog2e;
+      nl[rb] = -acc_read1<kPfLse + rb>() * kLog2e;
       if (h == 0) buf_store_f32(rd, (qrow[rb] + r) * 4, delta);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -178,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     };
     load_rows(std::integral_constant<int, 0>{});
     load_rows(std::integral_constant<int, 1>{});
+    FA4Q_STAMP(6);   // seg[6]: resident operands fetched, delta, scaled, pinned
     asm volatile("s_nop 4");  // v_accvgpr_write -> MFMA operand wait states (hipcc pads nothing around asm)
 
     // ---- loop-invariant per-lane LDS offsets ----
@@ -190,13 +256,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
 #pragma unroll
       for (int db = 0; db < C::DB; ++db) tr_off[x][db] = tr_lane_off<D>(lane, 8 * x, db);
 
-    f32x16 dqacc[2][C::DB];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dqacc[rb][db][i] = 0.f;
+    // dQ^T accumulators: block (row block rb, d block db) = a[16 (2 rb + db) ..] of the pinned file
+    static_for<2 * C::DB>([](auto i_) __attribute__((always_inline)) { acc_zero16<kAccBase + 16 * decltype(i_)::value>(); });
 
     // ---- pipeline state ----
     f32x16 S_[2], P_[2];   // [set]: score / dP accumulators of the block in flight; the other set holds the previous
@@ -219,6 +280,15 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
         if (dq4_cvt_tau(j) == tau) skb[j >> 2][j & 3] = pack2<T>(Y[2 * j], Y[2 * j + 1]);
     };
 
+    // dQ^T MFMA n = 2 e + db of a block of row block RB: (k-step e, d block db); sk[.][0] is complete first
+    auto dq_mfma = [&](auto rb_tag, int n, const u32x4 (&skb)[2]) __attribute__((always_inline)) {
+      constexpr int RB = decltype(rb_tag)::value;
+      const u32x4 kt = __builtin_bit_cast(u32x4, KT[n]);
+      if (n == 0) MfmaPin::template into<kAccBase + 32 * RB>((T*)nullptr, kt, skb[0]);
+      else if (n == 1) MfmaPin::template into<kAccBase + 32 * RB + 16>((T*)nullptr, kt, skb[0]);
+      else if (n == 2) MfmaPin::template into<kAccBase + 32 * RB>((T*)nullptr, kt, skb[1]);
+      else MfmaPin::template into<kAccBase + 32 * RB + 16>((T*)nullptr, kt, skb[1]);
+    };
     // One block iteration.  G: accumulator set of this block (the previous block's is G ^ 1); RB: its row block; PRB: the
     // previous block's row block; KTR: reload the K^T fragments (each right after the dQ MFMA that read the old one) from
     // `tb[x][db] + t_imm` = THIS key block; KRV: reload the K / V row fragments from `kb[ks] + k_imm` = the NEXT key
@@ -245,8 +315,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
         } else if (s == 6) { MfmaPin::template acc<8 * RB + 6>((T*)nullptr, P_[G], VR[2]);
         } else if (s == 7) { MfmaPin::template acc<8 * RB + 7>((T*)nullptr, P_[G], VR[3]);
         } else {   // (k-step e, d block db) = (n >> 1, n & 1): sk[.][0] is complete first
-          const int n = s - 2 * C::KS, e = n >> 1, db = n & 1;
-          dqacc[PRB][db] = T::mfma(KT[n], as_vec8<T>(sk[PG][e]), dqacc[PRB][db]);
+          dq_mfma(std::integral_constant<int, PRB>{}, s - 2 * C::KS, sk[PG]);
         }
         hook(s, 1);
         // ---- LDS reads into registers whose last use is just over ----
@@ -280,10 +349,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       constexpr int G = decltype(g_tag)::value, RB = decltype(rb_tag)::value;
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) {
-        if (s >= 2 * C::KS) {
-          const int n = s - 2 * C::KS, e = n >> 1, db = n & 1;
-          dqacc[RB][db] = T::mfma(KT[n], as_vec8<T>(sk[G][e]), dqacc[RB][db]);
-        }
+        if (s >= 2 * C::KS) dq_mfma(std::integral_constant<int, RB>{}, s - 2 * C::KS, sk[G]);
         block_valu(C::NS + s, S_[G], P_[G], sk[G], nl[RB]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -313,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    FA4Q_STAMP(7);   // seg[7]: first barrier
     // ---- fill: the first iteration's "previous block" is neutral (P = 0, dS = 0, zero fragments) ----
     {
 #pragma unroll
@@ -332,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    FA4Q_STAMP(0);
     // ---- the unmasked tiles: eight block iterations per tile, ring slots rotate ----
     int b0 = 0, b1 = 1, b2 = 2;   // ring slots of tiles t, t + 1, t + 2
     for (int t = 0; t < nfull; ++t) {
@@ -349,28 +417,42 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       // free here) -- the ring slot of tile t then takes tile t + 3
       auto hook_last = [&](int s, int phase) __attribute__((always_inline)) {
         if (phase == 0 && s == C::KS) {
+          FA4Q_ISTAMP(15);
           asm volatile("" ::: "memory");
           __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8), lgkmcnt(0)
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
+          FA4Q_ISTAMP(16);
         }
         if (phase == 1 && s == 5) dma_group(t + 3, b0, 0);
         if (phase == 1 && s == 9) dma_group(t + 3, b0, 1);
       };
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 0 * C::KBLK, kA, 0, hook_first);
+      FA4Q_ISTAMP(8);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 1 * C::KBLK, no_hook);
+      FA4Q_ISTAMP(9);
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 1 * C::KBLK, kA, 0, no_hook);
+      FA4Q_ISTAMP(10);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 2 * C::KBLK, no_hook);
+      FA4Q_ISTAMP(11);
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 2 * C::KBLK, kA, 0, no_hook);
+      FA4Q_ISTAMP(12);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 3 * C::KBLK, no_hook);
+      FA4Q_ISTAMP(13);
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 3 * C::KBLK, kA, 0, no_hook);
+      FA4Q_ISTAMP(14);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kN, 0, hook_last);
+      FA4Q_ISTAMP(15);
+#ifdef FA_STAMPS
+      ++ntile_;
+#endif
       const int bt = b0;
       b0 = b1;
       b1 = b2;
       b2 = bt;
     }
 
+    FA4Q_STAMP(1);
     if constexpr (!CAUSAL) {
       pipe_drain(I1{}, I1{});
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the (out-of-range) fetches past the last tile are over before the rings are reused
@@ -380,6 +462,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0), lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      // No vmcnt wait from here to the end of the pass: the place to request the NEXT pass's resident operands (its second
+      // pass, or the first pass of the workgroup's next item); they land during the nine block visits below.
+      if (pass + 1 < npass) prefetch(wk, pass + 1);
+      else if (item + (int)gridDim.x < n_items) prefetch(decode(item + (int)gridDim.x), 0);
+      __builtin_amdgcn_sched_barrier(0);
       // LDS byte offset of key block c = 0..7 of that region
       auto cbase = [&](int c) __attribute__((always_inline)) {
         return (c < C::NKB ? b0 * C::TILE_BYTES : b1 * C::TILE_BYTES - C::NKB * C::KBLK) + c * C::KBLK;
@@ -416,8 +503,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       tr_bases(tb, cbase(7 - wave));
       diag_start(1);
       block_iter(I0{}, I1{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, no_hook);
+      FA4Q_STAMP(2);
       pipe_drain(I0{}, I1{});
     }
+    FA4Q_STAMP(3);
 
     __syncthreads();  // every wave is out of the rings: they become the staging area
     if constexpr (FOLD) {
@@ -439,15 +528,48 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       }
     }
     FA_LDS char* stage = smem + wave * 32 * C::ROWB;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) store_tile_rows<D, T>(dqacc[rb], p.scale, stage, rdq, qrow[rb] * dq_rs, lane, dq_rs);
+    {
+      const f32x16 acc0[C::DB] = {acc_read16<kAccBase>(), acc_read16<kAccBase + 16>()};
+      store_tile_rows<D, T>(acc0, p.scale, stage, rdq, qrow[0] * dq_rs, lane, dq_rs);
+      const f32x16 acc1[C::DB] = {acc_read16<kAccBase + 32>(), acc_read16<kAccBase + 48>()};
+      store_tile_rows<D, T>(acc1, p.scale, stage, rdq, qrow[1] * dq_rs, lane, dq_rs);
+    }
+    __syncthreads();  // the staging area is the next pass's K ring again
+    FA4Q_STAMP(4);
+#ifdef FA_STAMPS
+    ++npass_;
+#endif
   }  // pass
+  }  // item
+#ifdef FA_STAMPS
+  if (p.dbg && (threadIdx.x & 63) == 0) {
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 32;
+    for (int i = 0; i < 17; ++i) d[i] = seg[i];
+    d[17] = ntile_;
+    unsigned long long clk1_, rt1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_)::"memory");
+    d[18] = clk1_ - clk0_;
+    d[19] = rt1_ - rt0_;
+    d[20] = npass_;
+  }
+#endif
 }
 
 template <typename T, bool CAUSAL>
 static hipError_t launch4(const BwdParams& p, hipStream_t s) {
   using C = Dq4Cfg;
-  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  if (CAUSAL) {   // persistent: one workgroup per CU walks the work list (a multiple of 8 keeps a workgroup on one XCD's items)
+    static std::atomic<int> cus{0};   // CU count of the device first launched on (devices of one node are alike)
+    int n = cus.load(std::memory_order_relaxed);
+    if (n == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+      n -= n % 8;
+      cus.store(n, std::memory_order_relaxed);
+    }
+    if (grid > n) grid = n;
+  }
   auto kern = fa_bwd_dq4_kernel<T, CAUSAL>;
   static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
   if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES, opted_in)) return e;

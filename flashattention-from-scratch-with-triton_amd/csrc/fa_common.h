@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace fa {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -93,43 +95,118 @@ typedef __attribute__((ext_vector_type(4))) unsigned agpr4_t;   // a 128-bit fra
 FA_MFMA_ASM_(mfma_v_bf16, "v_mfma_f32_32x32x16_bf16")
 FA_MFMA_ASM_(mfma_v_f16, "v_mfma_f32_32x32x16_f16")
 #undef FA_MFMA_ASM_
-// The same three forms with the B operand PINNED to literal accumulator registers: fragment F lives in
-// a[192 + 4F : 195 + 4F], F = 0..15 (fa_bwd_dq_v4.hip: its resident Q^T / dO^T fragments, 64 registers, do not fit beside
-// everything else that must sit in architectural VGPRs -- the A and B operands of an MFMA have independent AGPR bits, C and
-// D share one, so the row constants cannot follow).  Why literal names and not an "a" operand: hipcc splits the live range
-// of such an operand where it pleases and copies it back (v_accvgpr_write) right in front of the asm statement, whose
-// MFMA then reads the register inside the write's wait states -- hipcc pads no hazard for an asm statement (seen: a wrong
-// row block in the fp16 causal kernel).  Registers hipcc never allocates cannot be copied.  What guarantees that it never
-// does: tools/mfma_lint.py (CPU test) reads the code objects and fails if anything but pin_write() writes a[192:255]
-// or anything but an MFMA reads them.
-constexpr int kPinBase = 192;
-FA_DEVINL void pin_reserve() { asm volatile("" ::: "a192", "a255"); }   // the kernel descriptor allocates the whole AGPR file
-template <int F>
-FA_DEVINL void pin_write(u32x4 v) {
-  static_assert(F >= 0 && F < 16, "16 pinned fragments");
-  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\t"
-               "v_accvgpr_write_b32 a[%c7], %3"
-               :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 1),
-                  "i"(kPinBase + 4 * F + 2), "i"(kPinBase + 4 * F + 3));
+// ---- a PINNED accumulator file (fa_bwd_dq_v4.hip) ---------------------------------------------------------------------
+// One wave per SIMD owns 256 accumulator registers beside its 256 architectural ones, and everything a VGPR-form asm MFMA
+// touches except its A / B operands must be architectural (C and D share one AGPR bit).  The kernel therefore keeps what
+// does NOT need to be architectural in accumulator registers named LITERALLY in its asm statements:
+//     a[0:63]     the dQ^T accumulators: 4 blocks of 16 (row block, d block), accumulated by asm MFMAs
+//     a[64:127]   the resident B operands: 16 fragments of 4 (Q^T and dO^T k-steps of both row blocks)
+//     a[128:225]  prefetch registers: global loads that land in accumulator registers (a VMEM destination may be an AGPR
+//                 on gfx950) -- the NEXT pass's LSE rows (2) and Q / dO / O fragments (96), fetched during this pass
+//     a[226:255]  hipcc's
+// Why literal names and not "a" operands: hipcc splits the live range of such an operand where it pleases and copies it back
+// (v_accvgpr_write) right in front of the asm statement, whose MFMA then reads the register inside the write's wait states
+// -- hipcc pads no hazard for an asm statement (seen: a wrong row block in the fp16 causal kernel); and left to allocate the
+// accumulators itself it kept three copies of them for three code regions, 188 v_accvgpr_mov and 112 registers that the
+// prefetch needs.  Registers hipcc never allocates cannot be copied.  What keeps it out: FA_PIN_CLOBBERS on the statements
+// that bracket every long live range (each chain start, the prologue and epilogue statements), and what proves it stayed out:
+// tools/mfma_lint.py rule R4 (a CPU test) reads the code objects and fails on any other instruction that touches a[0:225].
+constexpr int kAccBase = 0, kPinBase = 64, kPfLse = 128, kPfBase = 130, kPinEnd = 226;
+#define FA_PIN_CLOBBERS \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", \
+  "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", \
+  "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", \
+  "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+  "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", \
+  "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", \
+  "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", \
+  "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+  "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", \
+  "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", \
+  "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", \
+  "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+  "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", \
+  "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", \
+  "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", \
+  "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+  "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", \
+  "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", \
+  "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225"
+FA_DEVINL void pin_reserve() { asm volatile("" ::: FA_PIN_CLOBBERS); }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
+template <int N, typename F>
+FA_DEVINL void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
-template <int F>
-FA_DEVINL u32x4 pin_read() {
-  u32x4 v;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\t"
-               "v_accvgpr_read_b32 %3, a[%c7]"
-               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
-               : "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 1), "i"(kPinBase + 4 * F + 2), "i"(kPinBase + 4 * F + 3));
+// prefetch loads (the caller counts them itself: vmcnt; s_nop 4: a descriptor fresh from a spill lane, see dma16 below) and
+// their read-back
+template <int A>
+FA_DEVINL void pf_load16(__amdgpu_buffer_rsrc_t r, int voff) {
+  static_assert(A >= kPfBase && A + 3 < kPinEnd, "prefetch register range");
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c2:%c3], %0, %1, 0 offen" :: "v"(voff), "s"(r), "i"(A), "i"(A + 3));
+}
+template <int A>
+FA_DEVINL void pf_load4(__amdgpu_buffer_rsrc_t r, int voff) {
+  static_assert(A >= kPfLse && A < kPfBase, "prefetch register range");
+  asm volatile("s_nop 4\n\tbuffer_load_dword a[%c2], %0, %1, 0 offen" :: "v"(voff), "s"(r), "i"(A));
+}
+template <int A>
+FA_DEVINL float acc_read1() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(A));
   return v;
 }
+template <int A>
+FA_DEVINL u32x4 acc_read4() {   // a[A : A + 3]
+  return u32x4{__builtin_bit_cast(unsigned, acc_read1<A>()), __builtin_bit_cast(unsigned, acc_read1<A + 1>()),
+               __builtin_bit_cast(unsigned, acc_read1<A + 2>()), __builtin_bit_cast(unsigned, acc_read1<A + 3>())};
+}
+template <int A>
+FA_DEVINL void acc_write4(u32x4 v) {   // a[A : A + 3]; the caller leaves the write -> MFMA wait states
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\t"
+               "v_accvgpr_write_b32 a[%c7], %3"
+               :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(A), "i"(A + 1), "i"(A + 2), "i"(A + 3));
+}
+template <int F> FA_DEVINL void pin_write(u32x4 v) { static_assert(F >= 0 && F < 16, "16 pinned fragments"); acc_write4<kPinBase + 4 * F>(v); }
+template <int F> FA_DEVINL u32x4 pin_read() { return acc_read4<kPinBase + 4 * F>(); }
+// a 16-register accumulator block a[A : A + 15]: zero, read out (after the last MFMA's 12+ wait states: the callers sit behind
+// a barrier)
+template <int A>
+FA_DEVINL void acc_zero16() {
+  static_for<4>([](auto q_) __attribute__((always_inline)) { acc_write4<A + 4 * decltype(q_)::value>(u32x4{0u, 0u, 0u, 0u}); });
+}
+template <int A>
+FA_DEVINL f32x16 acc_read16() {
+  f32x16 o;
+  static_for<4>([&](auto q_) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_)::value;
+    const u32x4 v = acc_read4<A + 4 * q>();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned w = v[j];   // (a copy: __builtin_bit_cast of the element expression itself reads element 0 every time)
+      o[4 * q + j] = __builtin_bit_cast(float, w);
+    }
+  });
+  return o;
+}
+// VGPR-form chain MFMAs with the B operand in pinned fragment F; `first` / `first0` carry the clobber list (one per chain
+// start = two per block iteration is dense enough: nothing hipcc parks lives shorter than that)
 #define FA_MFMA_ASM_PIN_(NAME, OP)                                                                                  \
   template <int F> FA_DEVINL void NAME##_first(f32x16& d, u32x4 a, const f32x16& c) {                              \
-    asm volatile(OP " %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3)); \
+    asm volatile(OP " %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3) : FA_PIN_CLOBBERS); \
   }                                                                                                                \
   template <int F> FA_DEVINL void NAME##_first0(f32x16& d, u32x4 a) {                                              \
-    asm volatile(OP " %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3)); \
+    asm volatile(OP " %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3) : FA_PIN_CLOBBERS); \
   }                                                                                                                \
   template <int F> FA_DEVINL void NAME##_acc(f32x16& d, u32x4 a) {                                                 \
     asm volatile(OP " %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(kPinBase + 4 * F), "i"(kPinBase + 4 * F + 3)); \
+  }                                                                                                                \
+  /* a[A : A + 15] += a . b, both operands architectural: the accumulating MFMAs (their chain needs no wait states) */ \
+  template <int A> FA_DEVINL void NAME##_into(u32x4 a, u32x4 b) {                                                  \
+    asm volatile(OP " a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(A), "i"(A + 15));                    \
   }
 FA_MFMA_ASM_PIN_(mfma_vp_bf16, "v_mfma_f32_32x32x16_bf16")
 FA_MFMA_ASM_PIN_(mfma_vp_f16, "v_mfma_f32_32x32x16_f16")
@@ -138,9 +215,11 @@ struct MfmaPin {   // T-dispatch of the forms above
   template <int F> static FA_DEVINL void first(BF16*, f32x16& d, u32x4 a, const f32x16& c) { mfma_vp_bf16_first<F>(d, a, c); }
   template <int F> static FA_DEVINL void first0(BF16*, f32x16& d, u32x4 a) { mfma_vp_bf16_first0<F>(d, a); }
   template <int F> static FA_DEVINL void acc(BF16*, f32x16& d, u32x4 a) { mfma_vp_bf16_acc<F>(d, a); }
+  template <int A> static FA_DEVINL void into(BF16*, u32x4 a, u32x4 b) { mfma_vp_bf16_into<A>(a, b); }
   template <int F> static FA_DEVINL void first(FP16*, f32x16& d, u32x4 a, const f32x16& c) { mfma_vp_f16_first<F>(d, a, c); }
   template <int F> static FA_DEVINL void first0(FP16*, f32x16& d, u32x4 a) { mfma_vp_f16_first0<F>(d, a); }
   template <int F> static FA_DEVINL void acc(FP16*, f32x16& d, u32x4 a) { mfma_vp_f16_acc<F>(d, a); }
+  template <int A> static FA_DEVINL void into(FP16*, u32x4 a, u32x4 b) { mfma_vp_f16_into<A>(a, b); }
 };
 template <typename A4> FA_DEVINL void BF16::mfma_v_first(f32x16& d, u32x4 a, A4 b, const f32x16& c) { mfma_v_bf16_first(d, a, b, c); }
 template <typename A4> FA_DEVINL void BF16::mfma_v_first0(f32x16& d, u32x4 a, A4 b) { mfma_v_bf16_first0(d, a, b); }
@@ -340,6 +419,10 @@ FA_DEVINL unsigned view_bytes(int rows, int rs, int rowb) {
   return (unsigned)(max(rows, 1) - 1) * rs + (unsigned)(min(rows, 1) * rowb);
 }
 
+// (Wait states inside the strings below: an M0 write needs one before the LDS-DMA that uses it, and a descriptor or scalar
+// offset that hipcc has just restored from a spill lane (v_readlane: a VALU write of an SGPR) needs five before a buffer
+// instruction reads it -- hipcc pads neither in front of an asm statement.  s_mov m0 + s_nop 3 covers both; a kernel with
+// many descriptors and 100+ SGPRs does spill them, and a stale descriptor is a memory fault, not a wrong number.)
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds): 64 lanes x 16 B from per-lane global offsets `voff`
 // (+ wave-uniform `soff`) to the 1 KiB of LDS starting at byte address `lds_addr` (wave-uniform).
 // Inline asm on purpose: the builtin form makes hipcc drain vmcnt(0) before any later LDS read it
@@ -349,7 +432,7 @@ FA_DEVINL unsigned view_bytes(int rows, int rs, int rowb) {
 FA_DEVINL void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, int voff, int soff) {
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
 }
@@ -363,14 +446,14 @@ template <int N>
 FA_DEVINL void dma_pieces(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, const int* voff, int soff) {
   static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 pieces per M0 setting (12-bit immediate offset)");
   if constexpr (N == 1) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff[0]), "s"(rsrc), "s"(soff));
   } else if constexpr (N == 2) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
                  "buffer_load_dwordx4 %2, %3, %4 offen offset:1024 lds"
                  :: "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff));
   } else {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
                  "buffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
                  "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\t"
                  "buffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds"

@@ -16,8 +16,12 @@ instruction = 1, a transcendental or an MFMA = 2, s_nop N = N + 1, an MFMA issue
   R1  no VALU instruction writes a register of the MFMA's A, B or C operand less than 2 wait states before it
   R2  nothing writes a register of its C operand (where C is not D) before the NEXT MFMA has issued
   R3  nothing but an MFMA reads or writes its D registers earlier than 12 wait states after it
-  R4  the pinned B-operand registers a[192:255] (fa_common.h pin_write) are written by exactly 64 v_accvgpr_write_b32 per
-      kernel that uses them and read only by MFMAs and (the scaled-Q workspace store) 0 or 32 v_accvgpr_read_b32
+  R5  no spill-lane restore (v_readlane / v_readfirstlane) of a descriptor or scalar offset less than 5 wait states before an
+      inline-asm buffer load that reads it (LDS-DMA, prefetch into accumulator registers): a stale descriptor is a memory fault
+  R4  the pinned accumulator file a[0:225] of fa_common.h is touched only by the instructions that own it: accumulators a[0:63]
+      by MFMAs, zeroing v_accvgpr_write_b32 and the epilogue's v_accvgpr_read_b32; resident operands a[64:127] by sets of 64
+      v_accvgpr_write_b32, MFMAs and sets of 32 v_accvgpr_read_b32; prefetch registers a[128:225] by buffer loads and sets of
+      98 v_accvgpr_read_b32 -- hipcc never allocates any of them
 
 The model is linear (it follows the instruction stream, not branches): a hazard across a taken branch is not seen.
 Not part of the product; tests/test_codeobj.py runs it.
@@ -32,8 +36,19 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import codeobj  # noqa: E402
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-PIN_LO, PIN_HI = 192, 255
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1):
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
 
 
 def regs(text):
@@ -101,12 +116,19 @@ def disassemble(elf):
 
 def lint_kernel(insts):
     bad = []
+    # a kernel on the pinned accumulator file issues ALL its MFMAs as inline asm (fa_common.h)
+    all_asm = any(i.is_mfma and len(i.ops) >= 4 and i.ops[0].startswith("v") and regs(i.ops[2]) & {("a", k) for k in range(64, 128)} for i in insts)
     for k, m in enumerate(insts):
         if not m.is_mfma or len(m.ops) < 4:
             continue
         d, a, b, c = (regs(o) for o in m.ops[:4])
-        if not d or any(f != "v" for f, _ in d):
-            continue   # AGPR accumulator: hipcc's own MFMA, hipcc's padding
+        if not d:
+            continue
+        if any(f != "v" for f, _ in d):
+            if not all_asm:
+                continue   # AGPR accumulator: hipcc's own MFMA, hipcc's padding
+            c = set()      # a pinned accumulator of an all-asm kernel: only R1 on A / B applies (its chain is MFMA-only)
+            d = set()
         # R1: VALU writes of A / B / C in front
         ws, j = 0, k - 1
         while j >= 0 and ws < 2:
@@ -131,16 +153,48 @@ def lint_kernel(insts):
                 seen_next = True
             if t >= 12 and seen_next:
                 break
-    # R4: the pinned registers
-    pinned = {("a", i) for i in range(PIN_LO, PIN_HI + 1)}
-    wr = [i for i in insts if i.writes & pinned]
-    rd = [i for i in insts if i.reads & pinned and not i.is_mfma]
-    if wr or rd or any(i.is_mfma and i.reads & pinned for i in insts):
-        if len(wr) != 64 or any(i.op != "v_accvgpr_write_b32" for i in wr):
-            bad.append("R4 a[%d:%d] written by %d instructions (%s), expected the 64 v_accvgpr_write_b32 of pin_write" % (
-                PIN_LO, PIN_HI, len(wr), sorted({i.op for i in wr})))
-        if len(rd) not in (0, 32) or any(i.op != "v_accvgpr_read_b32" for i in rd):
-            bad.append("R4 a[%d:%d] read by %d non-MFMA instructions (%s)" % (PIN_LO, PIN_HI, len(rd), sorted({i.op for i in rd})))
+    # R5: an inline-asm buffer load (LDS-DMA, or an accumulator-register destination: hipcc emits neither) whose descriptor or
+    # scalar offset was written by a VALU instruction (v_readlane / v_readfirstlane: a spill-lane restore) < 5 wait states before
+    for k, m in enumerate(insts):
+        if not m.op.startswith("buffer_load") or not ("lds" in m.ops or (m.ops and m.ops[0].startswith("a"))):
+            continue
+        need = set()
+        for o in m.ops[1:]:
+            need |= sregs(o)
+        ws, j = 0, k - 1
+        while j >= 0 and ws < 5:
+            q = insts[j]
+            if q.op.startswith(("v_readlane", "v_readfirstlane")) and q.ops and sregs(q.ops[0]) & need:
+                bad.append("R5 %s %s  <- %s %s (%d wait states before)" % (m.op, ", ".join(m.ops), q.op, ", ".join(q.ops), ws))
+            ws += q.ws
+            j -= 1
+    # R4: the pinned accumulator file a[0:225] (fa_common.h): accumulators a[0:63], resident B operands a[64:127], prefetch
+    # registers a[128:225].  A kernel uses it iff one of its VGPR-form MFMAs takes its B operand from a[64:127].
+    acc = {("a", i) for i in range(0, 64)}
+    res = {("a", i) for i in range(64, 128)}
+    pf = {("a", i) for i in range(128, 226)}
+    uses = any(i.is_mfma and len(i.ops) >= 4 and i.ops[0].startswith("v") and regs(i.ops[2]) & res for i in insts)
+    if uses:
+        def ops_of(sel):
+            return sorted({i.op for i in sel})
+        wr = [i for i in insts if i.writes & acc and not i.is_mfma]
+        if any(i.op != "v_accvgpr_write_b32" for i in wr) or len(wr) % 64:
+            bad.append("R4 a[0:63] written by %d non-MFMA instructions (%s), expected sets of 64 zeroing v_accvgpr_write_b32" % (len(wr), ops_of(wr)))
+        rd = [i for i in insts if i.reads & acc and not i.is_mfma]
+        if any(i.op != "v_accvgpr_read_b32" for i in rd) or len(rd) % 64:
+            bad.append("R4 a[0:63] read by %d non-MFMA instructions (%s), expected sets of 64 v_accvgpr_read_b32" % (len(rd), ops_of(rd)))
+        wr = [i for i in insts if i.writes & res]
+        if not wr or len(wr) % 64 or any(i.op != "v_accvgpr_write_b32" for i in wr):
+            bad.append("R4 a[64:127] written by %d instructions (%s), expected sets of 64 v_accvgpr_write_b32" % (len(wr), ops_of(wr)))
+        rd = [i for i in insts if i.reads & res and not i.is_mfma]
+        if len(rd) % 32 or any(i.op != "v_accvgpr_read_b32" for i in rd):
+            bad.append("R4 a[64:127] read by %d non-MFMA instructions (%s)" % (len(rd), ops_of(rd)))
+        wr = [i for i in insts if i.writes & pf]
+        if any(i.op not in ("buffer_load_dwordx4", "buffer_load_dword") for i in wr):
+            bad.append("R4 a[128:225] written by %s, expected the prefetch loads only" % ops_of(wr))
+        rd = [i for i in insts if i.reads & pf]
+        if any(i.op != "v_accvgpr_read_b32" for i in rd) or (wr and len(rd) % 98):
+            bad.append("R4 a[128:225] read by %d instructions (%s), expected sets of 98 v_accvgpr_read_b32" % (len(rd), ops_of(rd)))
     return bad
 
 
