@@ -46,7 +46,11 @@ struct Dq4Cfg {
   static constexpr int TILE_BYTES = BN * ROWB;              // 16 KiB
   static constexpr int NBUF = 3;
   static constexpr int V_BASE = NBUF * TILE_BYTES;          // K[NBUF], then V[NBUF]
-  static constexpr int LDS_BYTES = 2 * NBUF * TILE_BYTES;   // 96 KiB
+  // behind the ring: the NEXT pass's Q and dO rows, 64 per wave (row blocks w and 7 - w, 32 rows x 128 B each), staged by
+  // LDS-DMA; its O rows are staged in the ring slot that is free when they arrive (the kernel says where)
+  static constexpr int QS_OFF = 2 * NBUF * TILE_BYTES, DOS_OFF = QS_OFF + BM * ROWB;
+  static constexpr int RB_BYTES = 32 * ROWB;                // one row block's rows: 4 KiB = 4 pieces
+  static constexpr int LDS_BYTES = DOS_OFF + BM * ROWB;     // 160 KiB: the whole LDS of a CU
   static constexpr int PIECES = TILE_BYTES / (NW * 1024);   // 1-KiB LDS-DMA pieces per wave per matrix (4)
   static constexpr int RPI = 1024 / ROWB;                   // tile rows per piece
   static constexpr int NS = 2 * KS + 2 * DB;                // MFMA slots per block iteration (12)
@@ -126,35 +130,52 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
   auto tile_of = [&](const Work& wk, int pass) __attribute__((always_inline)) -> int {   // heavy tile first
     return paired ? (pass == 0 ? nq - 1 - wk.idx : wk.idx) : (CAUSAL ? nq - 1 - wk.idx : wk.idx);
   };
-  // The resident operands of a pass -- this lane's Q, dO and O fragments of both row blocks (24 x 16 bytes) and its two LSE
-  // rows -- are requested a whole phase before the pass needs them, into the prefetch accumulator registers of fa_common.h
-  // (Q k-step ks of row block rb -> a[96 + 48 rb + 4 ks ..], dO + 16, O + 32; LSE -> a[92 + rb]).  Why: these rows are cold
-  // (nobody else reads them), every workgroup of a launch starts a pass at about the same moment, and 256 CUs asking for
-  // 96 KiB each is an HBM burst: issuing the 26 loads took a wave 8k cycles of a 75k-cycle pass (stamps, tools/stamps_dq4.py),
-  // with nothing else resident on the CU to cover them; without the traffic the kernel ran 11 % faster.  Issued from inside
-  // the previous pass they cost their issue slots only, and the HBM sees them spread over the whole launch.
-  auto prefetch = [&](const Work& wk, int pass) __attribute__((always_inline)) {
-    const int ln = lane_id_now(), r = ln & 31, h = ln >> 5;
+  // The resident operands of a pass -- Q, dO (MFMA B operands) and O (delta) of this wave's 64 rows, and their LSE -- are
+  // STAGED through LDS a whole phase before the pass needs them: the rows are cold (nobody else reads them), every workgroup
+  // of a launch starts a pass at about the same moment, and fetched as fragments -- 26 loads per lane, each touching 32
+  // cache lines -- they cost a wave 8k cycles of a 75k-cycle pass wherever they are issued (the CU's address unit takes ~63
+  // cycles per such load: stamps, tools/stamps_dq4.py; without the traffic the kernel ran 11 % faster).  As LDS-DMA pieces
+  // (8 whole rows each, the K / V tile machinery) they cost ~27 cycles of the address unit apiece, no register, and ride in
+  // slots of the previous pass's last block iterations; the fragments are then ds_read_b128 row reads like K's.
+  // Six groups of four pieces per wave: g = 0, 1 Q rows of row block 0, 1 -> QS; 2, 3 dO -> DOS; 4 O of row block 0 -> this
+  // wave's rows of the K half of ring slot `oslot`, 5 O of row block 1 -> its rows of the V half: exactly the 2 x 4 KiB this
+  // wave fills itself with the pass's third tile, once it has consumed them -- no other wave ever touches them.
+  struct Stage {
+    __amdgpu_buffer_rsrc_t rq, rdo, ro, rl;
+    int row0[2];
+  };
+  auto stage_of = [&](const Work& wk, int pass, bool valid) __attribute__((always_inline)) -> Stage {
     const int q0 = tile_of(wk, pass) * C::BM;
-    const int row[2] = {q0 + 32 * wave + r, q0 + 32 * (7 - wave) + r};
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + wk.b * p.lq.sb + wk.h * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
-    const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + wk.b * p.ldo.sb + wk.h * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)p.o + wk.b * p.lo.sb + wk.h * p.lo.sh, view_bytes(Sq, o_rs, C::ROWB));
-    const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + wk.b * p.lse_sb + wk.h * p.lse_sh, (unsigned)Sq * 4);
-    static_for<2 * C::KS>([&](auto i_) __attribute__((always_inline)) {
-      constexpr int i = decltype(i_)::value, rb = i / C::KS, ks = i % C::KS, A = kPfBase + 48 * rb + 4 * ks;
-      const int col = (2 * ks + h) * 16;
-      pf_load16<A>(rq, row[rb] * q_rs + col);
-      pf_load16<A + 16>(rdo, row[rb] * do_rs + col);
-      pf_load16<A + 32>(ro, row[rb] * o_rs + col);
-    });
-    pf_load4<kPfLse>(rl, row[0] * 4);
-    pf_load4<kPfLse + 1>(rl, row[1] * 4);
+    // an invalid stage (nothing follows this pass) has empty descriptors: its pieces fetch nothing
+    const unsigned nb = valid ? view_bytes(Sq, q_rs, C::ROWB) : 0u, nbd = valid ? view_bytes(Sq, do_rs, C::ROWB) : 0u;
+    const unsigned nbo = valid ? view_bytes(Sq, o_rs, C::ROWB) : 0u, nbl = valid ? (unsigned)Sq * 4 : 0u;
+    return Stage{make_rsrc((const char*)p.q + wk.b * p.lq.sb + wk.h * p.lq.sh, nb),
+                 make_rsrc((const char*)p.dout + wk.b * p.ldo.sb + wk.h * p.ldo.sh, nbd),
+                 make_rsrc((const char*)p.o + wk.b * p.lo.sb + wk.h * p.lo.sh, nbo),
+                 make_rsrc(p.lse + wk.b * p.lse_sb + wk.h * p.lse_sh, nbl),
+                 {q0 + 32 * wave, q0 + 32 * (7 - wave)}};
+  };
+  auto stage_group = [&](const Stage& st, int oslot, int g) __attribute__((always_inline)) {
+    const int ln = lane_id_now(), prow = ln >> 3;                     // piece i holds rows 8 i + prow of the row block
+    const int rb = g & 1, rs = g < 2 ? q_rs : (g < 4 ? do_rs : o_rs);
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // (dma_pieces: the immediate 1024 i moves LDS and global address together: taken out here)
+      voff[i] = (st.row0[rb] + 8 * i + prow) * rs + swz_chunk<D>(8 * i + prow, ln & 7) * 16 - 1024 * i;
+    const int dst = g < 4 ? (g < 2 ? C::QS_OFF : C::DOS_OFF) + (2 * wave + rb) * C::RB_BYTES
+                          : (rb ? C::V_BASE : 0) + oslot * C::TILE_BYTES + wave * C::RB_BYTES;
+    dma_pieces<4>(g < 2 ? st.rq : (g < 4 ? st.rdo : st.ro), (unsigned)(lds0 + dst), voff, 0);
+  };
+  auto stage_lse = [&](const Stage& st) __attribute__((always_inline)) {   // the two LSE rows of this lane: a[128], a[129]
+    const int r = lane_id_now() & 31;
+    pf_load4<kPfLse>(st.rl, (st.row0[0] + r) * 4);
+    pf_load4<kPfLse + 1>(st.rl, (st.row0[1] + r) * 4);
   };
 
   int item = blockIdx.x;
   Work wk = decode(item);
-  prefetch(wk, 0);   // the first pass of a workgroup: no previous pass to hide behind
+  int b0 = 0, b1 = 1, b2 = 2;   // ring slots of tiles t, t + 1, t + 2; they keep rotating from pass to pass
+  bool staged = false;          // this pass's rows are on their way (issued from inside the previous pass)
   for (; item < n_items; item += gridDim.x, wk = decode(min(item, n_items - 1))) {
   const int b_ = wk.b, h_ = wk.h, npass = wk.npass;
   const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + b_ * p.ldq.sb + h_ * p.ldq.sh, view_bytes(Sq, dq_rs, C::ROWB));
@@ -197,29 +218,39 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     // 256 ARCHITECTURAL registers (C and D share one AGPR bit), which these 64 registers would overflow.
     float nl[2];       // -LSE * log2e of this lane's row
     f32x16 NL[FOLD ? 2 : 1], ND[2];   // the same / -delta in every register: C operands of the chain starts
-    // the ring: tiles 0 and 1 whole and the part of tile 2 that a steady-state tile step issues in its last iteration
+    if (!staged) {   // the first pass of a workgroup (and every pass of a non-causal launch): nothing to hide behind
+      const Stage st = stage_of(wk, pass, true);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) dma_group(0, 0, g4);
+      for (int g = 0; g < 6; ++g) stage_group(st, b2, g);
+      stage_lse(st);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's staged rows have landed (and the previous pass's stores)
+    // the ring: tiles 0 and 1 now (their address-unit time runs under the arithmetic below); tile 2's first half follows once
+    // this wave has consumed the O rows that sit in its part of slot b2, the second half rides in the first tile step
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) dma_group(1, 1, g4);
-    dma_group(2, 2, 0);
-    dma_group(2, 2, 1);
-    FA4Q_STAMP(5);   // seg[5]: ring primed (20 pieces issued)
-    // everything older than those 20 pieces has landed: the prefetch loads of this pass (and the previous pass's stores)
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    for (int g4 = 0; g4 < 4; ++g4) dma_group(0, b0, g4);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) dma_group(1, b1, g4);
+    FA4Q_STAMP(5);   // seg[5]: staged rows landed, tiles 0 and 1 requested
     __builtin_amdgcn_sched_barrier(0);
+    int row_off[C::KS];   // A-operand row reads (K rows and V rows; here: the staged Q / dO / O rows)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
     auto load_rows = [&](auto rb_tag) __attribute__((always_inline)) {
       constexpr int rb = decltype(rb_tag)::value;
       float dsum = 0.f;
       vec8 qv[C::KS], dv[C::KS];
-      static_for<C::KS>([&](auto ks_) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ks_)::value, A = kPfBase + 48 * rb + 4 * ks;
-        qv[ks] = as_vec8<T>(acc_read4<A>());
-        dv[ks] = as_vec8<T>(acc_read4<A + 16>());
-        const vec8 ov = as_vec8<T>(acc_read4<A + 32>());
+      const FA_LDS char* qs = smem + C::QS_OFF + (2 * wave + rb) * C::RB_BYTES;
+      const FA_LDS char* ds = smem + C::DOS_OFF + (2 * wave + rb) * C::RB_BYTES;
+      const FA_LDS char* os = smem + (rb ? C::V_BASE : 0) + b2 * C::TILE_BYTES + wave * C::RB_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        qv[ks] = as_vec8<T>(lds_read16(qs + row_off[ks]));
+        dv[ks] = as_vec8<T>(lds_read16(ds + row_off[ks]));
+        const vec8 ov = as_vec8<T>(lds_read16(os + row_off[ks]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsum = __builtin_fmaf((float)dv[ks][j], (float)ov[j], dsum);
-      });
+      }
       const float delta = half_sum(dsum);
       nl[rb] = -acc_read1<kPfLse + rb>() * kLog2e;
       if (h == 0) buf_store_f32(rd, (qrow[rb] + r) * 4, delta);
@@ -243,13 +274,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     };
     load_rows(std::integral_constant<int, 0>{});
     load_rows(std::integral_constant<int, 1>{});
-    FA4Q_STAMP(6);   // seg[6]: resident operands fetched, delta, scaled, pinned
+    // the O rows are consumed (every LDS read above has fed arithmetic): this wave's part of slot b2 takes tile 2
+    __builtin_amdgcn_sched_barrier(0);
+    dma_group(2, b2, 0);
+    dma_group(2, b2, 1);
+    FA4Q_STAMP(6);   // seg[6]: delta, scaled, pinned; tile 2's first half requested
     asm volatile("s_nop 4");  // v_accvgpr_write -> MFMA operand wait states (hipcc pads nothing around asm)
 
     // ---- loop-invariant per-lane LDS offsets ----
-    int row_off[C::KS];   // A-operand row reads (K rows and V rows)
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
     int tr_off[2][C::DB];  // transposed reads of K
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -393,15 +425,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       for (int n = 0; n < 2 * C::DB; ++n) KT[n] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        KR[ks] = lds_read16(smem + row_off[ks]);
-        VR[ks] = lds_read16(smem + C::V_BASE + row_off[ks]);
+        KR[ks] = lds_read16(smem + b0 * C::TILE_BYTES + row_off[ks]);
+        VR[ks] = lds_read16(smem + C::V_BASE + b0 * C::TILE_BYTES + row_off[ks]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 
     FA4Q_STAMP(0);
     // ---- the unmasked tiles: eight block iterations per tile, ring slots rotate ----
-    int b0 = 0, b1 = 1, b2 = 2;   // ring slots of tiles t, t + 1, t + 2
     for (int t = 0; t < nfull; ++t) {
       int kA[C::KS], kN[C::KS], tA[2][C::DB];
       row_bases(kA, b0 * C::TILE_BYTES);
@@ -462,11 +493,26 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0), lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // No vmcnt wait from here to the end of the pass: the place to request the NEXT pass's resident operands (its second
-      // pass, or the first pass of the workgroup's next item); they land during the nine block visits below.
-      if (pass + 1 < npass) prefetch(wk, pass + 1);
-      else if (item + (int)gridDim.x < n_items) prefetch(decode(item + (int)gridDim.x), 0);
-      __builtin_amdgcn_sched_barrier(0);
+      // No vmcnt wait from here to the end of the pass and ring slot b2 is free: the place to stage the NEXT pass's rows (the
+      // pair's second pass, or the first pass of the workgroup's next item).  The six piece groups ride in the three block
+      // iterations below that every wave executes exactly once; with nothing to follow the descriptors are empty.
+      const bool more_pass = pass + 1 < npass, more_item = item + (int)gridDim.x < n_items;
+      const Stage nst = stage_of(more_pass ? wk : decode(min(item + (int)gridDim.x, n_items - 1)), more_pass ? pass + 1 : 0,
+                                 more_pass || more_item);
+      auto hook_a = [&](int s, int phase) __attribute__((always_inline)) {
+        if (phase == 1 && s == 2) stage_group(nst, b2, 0);
+        if (phase == 1 && s == 8) stage_group(nst, b2, 1);
+      };
+      auto hook_b = [&](int s, int phase) __attribute__((always_inline)) {
+        if (phase == 1 && s == 2) stage_group(nst, b2, 2);
+        if (phase == 1 && s == 8) stage_group(nst, b2, 3);
+      };
+      auto hook_c = [&](int s, int phase) __attribute__((always_inline)) {
+        if (phase == 1 && s == 2) stage_group(nst, b2, 4);
+        if (phase == 1 && s == 6) stage_group(nst, b2, 5);
+        if (phase == 1 && s == 10) stage_lse(nst);
+      };
+      staged = more_pass || more_item;
       // LDS byte offset of key block c = 0..7 of that region
       auto cbase = [&](int c) __attribute__((always_inline)) {
         return (c < C::NKB ? b0 * C::TILE_BYTES : b1 * C::TILE_BYTES - C::NKB * C::KBLK) + c * C::KBLK;
@@ -489,8 +535,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       tr_bases(tb, cbase(c));
       row_bases(kb, cbase(c + 1));
       diag_start(0);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, no_hook);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, no_hook);
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_a);
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, hook_b);
       // row block 1 alone: key blocks wave + 1 .. 6 - wave (an even number), then its diagonal block 7 - wave
       for (c = wave + 1; c < 7 - wave; c += 2) {
         tr_bases(tb, cbase(c));
@@ -502,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       }
       tr_bases(tb, cbase(7 - wave));
       diag_start(1);
-      block_iter(I0{}, I1{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, no_hook);
+      block_iter(I0{}, I1{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_c);
       FA4Q_STAMP(2);
       pipe_drain(I0{}, I1{});
     }
@@ -527,14 +573,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
         put(1, 3, pin_read<11>());
       }
     }
-    FA_LDS char* stage = smem + wave * 32 * C::ROWB;
+    // staged in this wave's rows of the K half of slot b0 (dead since the barrier above; the wave's own next fetch goes there)
+    FA_LDS char* stage = smem + b0 * C::TILE_BYTES + wave * C::RB_BYTES;
     {
       const f32x16 acc0[C::DB] = {acc_read16<kAccBase>(), acc_read16<kAccBase + 16>()};
       store_tile_rows<D, T>(acc0, p.scale, stage, rdq, qrow[0] * dq_rs, lane, dq_rs);
       const f32x16 acc1[C::DB] = {acc_read16<kAccBase + 32>(), acc_read16<kAccBase + 48>()};
       store_tile_rows<D, T>(acc1, p.scale, stage, rdq, qrow[1] * dq_rs, lane, dq_rs);
     }
-    __syncthreads();  // the staging area is the next pass's K ring again
     FA4Q_STAMP(4);
 #ifdef FA_STAMPS
     ++npass_;

@@ -20,8 +20,8 @@ instruction = 1, a transcendental or an MFMA = 2, s_nop N = N + 1, an MFMA issue
       inline-asm buffer load that reads it (LDS-DMA, prefetch into accumulator registers): a stale descriptor is a memory fault
   R4  the pinned accumulator file a[0:225] of fa_common.h is touched only by the instructions that own it: accumulators a[0:63]
       by MFMAs, zeroing v_accvgpr_write_b32 and the epilogue's v_accvgpr_read_b32; resident operands a[64:127] by sets of 64
-      v_accvgpr_write_b32, MFMAs and sets of 32 v_accvgpr_read_b32; prefetch registers a[128:225] by buffer loads and sets of
-      98 v_accvgpr_read_b32 -- hipcc never allocates any of them
+      v_accvgpr_write_b32, MFMAs and sets of 32 v_accvgpr_read_b32; prefetch registers a[128:225] by buffer loads and
+      v_accvgpr_read_b32 -- hipcc never allocates any of them
 
 The model is linear (it follows the instruction stream, not branches): a hazard across a taken branch is not seen.
 Not part of the product; tests/test_codeobj.py runs it.
@@ -193,8 +193,8 @@ def lint_kernel(insts):
         if any(i.op not in ("buffer_load_dwordx4", "buffer_load_dword") for i in wr):
             bad.append("R4 a[128:225] written by %s, expected the prefetch loads only" % ops_of(wr))
         rd = [i for i in insts if i.reads & pf]
-        if any(i.op != "v_accvgpr_read_b32" for i in rd) or (wr and len(rd) % 98):
-            bad.append("R4 a[128:225] read by %d instructions (%s), expected sets of 98 v_accvgpr_read_b32" % (len(rd), ops_of(rd)))
+        if any(i.op != "v_accvgpr_read_b32" for i in rd) or (wr and len(rd) % 2):
+            bad.append("R4 a[128:225] read by %d instructions (%s), expected v_accvgpr_read_b32 only" % (len(rd), ops_of(rd)))
     return bad
 
 
