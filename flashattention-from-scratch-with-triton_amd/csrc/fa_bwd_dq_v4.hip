@@ -86,6 +86,20 @@ constexpr int dq4_cvt_tau(int j) { return j == 0 ? 13 : 14 + (j - 1) / 2; }
 #define FA4Q_ISTAMP(slot) do {} while (0)
 #endif
 
+// Where a tile's eight LDS-DMA pieces per wave are issued.  Grouped (the dK/dV family-3 placement): two pairs in the last
+// iteration of a tile step, two in the first of the next.  Spread (A/B hook, OFF): one piece per block iteration, on the theory
+// that four waves x four pieces at once queue up in the CU's one address unit (the two iterations that carry them stamp
+// 250-300 cycles above the others) -- measured 0.4135 vs 0.3463 ms at the headline, 0.7138 vs 0.6533 non-causal: every
+// separate issue point costs more than the queue does (profiles/r04_ab_lines.txt).
+#ifndef FA_DQ4_DMA_SPREAD
+#define FA_DQ4_DMA_SPREAD 0
+#endif
+#ifndef FA_DQ4_SPREAD_SLOT
+#define FA_DQ4_SPREAD_SLOT 2
+#endif
+constexpr bool kDq4Spread = FA_DQ4_DMA_SPREAD != 0;
+constexpr int kDq4SpreadSlot = FA_DQ4_SPREAD_SLOT;
+
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
 #ifdef FA_STAMPS
@@ -211,6 +225,15 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       if (g4 < 2) dma_pieces<2>(rk, (unsigned)(lds0 + dst), dma_src + i, soff);
       else dma_pieces<2>(rv, (unsigned)(lds0 + C::V_BASE + dst), dma_src + i, soff);
     };
+    // one piece: j = 0..3 the K pieces, 4..7 the V pieces of this wave's share
+    auto dma_piece1 = [&](int t, int buf, int j) __attribute__((always_inline)) {
+      const int i = j & 3;
+      const int dst = buf * C::TILE_BYTES + ((C::BN / C::NW) * wave + C::RPI * i) * C::ROWB;
+      const int soff = t < ntot ? t * C::BN * kv_rs : C::kOOB;
+      const int v = dma_src[i] + 1024 * (i & 1);
+      if (j < 4) dma_pieces<1>(rk, (unsigned)(lds0 + dst), &v, soff);
+      else dma_pieces<1>(rv, (unsigned)(lds0 + C::V_BASE + dst), &v, soff);
+    };
 
     // ---- resident B operands: Q^T and dO^T fragments of both row blocks; delta (K:210-211, from the rounded O) ----
     // They live in the pinned accumulator registers of fa_common.h (pin_write / MfmaPin): fragment F = 8 rb + ks holds
@@ -224,7 +247,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       for (int g = 0; g < 6; ++g) stage_group(st, b2, g);
       stage_lse(st);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's staged rows have landed (and the previous pass's stores)
+    // this wave's staged rows have landed: everything but the previous pass's epilogue stores, which are younger -- 8 dQ
+    // stores (+ 8 of the scaled-Q workspace) -- and whose write acknowledgements are not worth 1-2k cycles of waiting
+    if (!staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (FOLD && p.qs) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     // the ring: tiles 0 and 1 now (their address-unit time runs under the arithmetic below); tile 2's first half follows once
     // this wave has consumed the O rows that sit in its part of slot b2, the second half rides in the first tile step
 #pragma unroll
@@ -276,8 +303,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     load_rows(std::integral_constant<int, 1>{});
     // the O rows are consumed (every LDS read above has fed arithmetic): this wave's part of slot b2 takes tile 2
     __builtin_amdgcn_sched_barrier(0);
-    dma_group(2, b2, 0);
-    dma_group(2, b2, 1);
+    if constexpr (!kDq4Spread) {
+      dma_group(2, b2, 0);
+      dma_group(2, b2, 1);
+    }
     FA4Q_STAMP(6);   // seg[6]: delta, scaled, pinned; tile 2's first half requested
     asm volatile("s_nop 4");  // v_accvgpr_write -> MFMA operand wait states (hipcc pads nothing around asm)
 
@@ -440,8 +469,21 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       tr_bases(tA, b0 * C::TILE_BYTES);
       // tile t + 2's V pairs ride in the first iteration (its K pairs went out in the previous tile's last one)
       auto hook_first = [&](int s, int phase) __attribute__((always_inline)) {
-        if (phase == 1 && s == 1) dma_group(t + 2, b2, 2);
-        if (phase == 1 && s == 5) dma_group(t + 2, b2, 3);
+        if constexpr (kDq4Spread) {
+          if (phase == 1 && s == kDq4SpreadSlot) dma_piece1(t + 2, b2, 0);
+        } else {
+          if (phase == 1 && s == 1) dma_group(t + 2, b2, 2);
+          if (phase == 1 && s == 5) dma_group(t + 2, b2, 3);
+        }
+      };
+      // (spread placement: piece I of tile t + 2 rides in block iteration I, all of them in front of this step's commit)
+      auto hook_mid = [&](auto i_tag) __attribute__((always_inline)) {
+        return [&, i_tag](int s, int phase) __attribute__((always_inline)) {
+          constexpr int I = decltype(i_tag)::value;
+          if constexpr (kDq4Spread) {
+            if (phase == 1 && s == kDq4SpreadSlot) dma_piece1(t + 2, b2, I);
+          }
+        };
       };
       // the commit: tile t + 1 has landed for every wave (vmcnt(8): the eight pieces of tile t + 2 may still fly) and every
       // wave's reads of tile t are complete (the youngest, K^T of its last key block, are four slots old: lgkmcnt(0) is
@@ -455,22 +497,26 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
           asm volatile("" ::: "memory");
           FA4Q_ISTAMP(16);
         }
-        if (phase == 1 && s == 5) dma_group(t + 3, b0, 0);
-        if (phase == 1 && s == 9) dma_group(t + 3, b0, 1);
+        if constexpr (kDq4Spread) {
+          if (phase == 1 && s == 1) dma_piece1(t + 2, b2, 7);
+        } else {
+          if (phase == 1 && s == 5) dma_group(t + 3, b0, 0);
+          if (phase == 1 && s == 9) dma_group(t + 3, b0, 1);
+        }
       };
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 0 * C::KBLK, kA, 0, hook_first);
       FA4Q_ISTAMP(8);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 1 * C::KBLK, no_hook);
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 1 * C::KBLK, hook_mid(std::integral_constant<int, 1>{}));
       FA4Q_ISTAMP(9);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 1 * C::KBLK, kA, 0, no_hook);
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 1 * C::KBLK, kA, 0, hook_mid(std::integral_constant<int, 2>{}));
       FA4Q_ISTAMP(10);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 2 * C::KBLK, no_hook);
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 2 * C::KBLK, hook_mid(std::integral_constant<int, 3>{}));
       FA4Q_ISTAMP(11);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 2 * C::KBLK, kA, 0, no_hook);
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 2 * C::KBLK, kA, 0, hook_mid(std::integral_constant<int, 4>{}));
       FA4Q_ISTAMP(12);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 3 * C::KBLK, no_hook);
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 3 * C::KBLK, hook_mid(std::integral_constant<int, 5>{}));
       FA4Q_ISTAMP(13);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 3 * C::KBLK, kA, 0, no_hook);
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 3 * C::KBLK, kA, 0, hook_mid(std::integral_constant<int, 6>{}));
       FA4Q_ISTAMP(14);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kN, 0, hook_last);
       FA4Q_ISTAMP(15);
