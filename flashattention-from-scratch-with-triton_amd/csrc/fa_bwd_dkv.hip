@@ -311,9 +311,11 @@ static hipError_t launch(const BwdParams& p, hipStream_t s) {
 
 hipError_t launch_bwd_dkv_v2(BwdParams p, int D, int dtype, int causal, hipStream_t s);  // fa_bwd_dkv_v2.hip
 hipError_t launch_bwd_dkv_v3(BwdParams p, int dtype, int causal, hipStream_t s);         // fa_bwd_dkv_v3.hip
+hipError_t launch_bwd_dkv_v4(BwdParams p, int dtype, int causal, hipStream_t s);         // fa_bwd_dkv_v4.hip
 
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s) {
-  const int impl = p.drop.thresh ? 1 : pick_dkv_impl(g_force_dkv, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0);
+  const int impl = p.drop.thresh ? 1 : pick_dkv_impl(g_force_dkv, D, dtype, p.B, p.H, p.Sq, p.Sk, causal != 0, !p.vl.cu_q);
+  if (impl == 4) return launch_bwd_dkv_v4(p, dtype, causal, s);
   if (impl == 2) return launch_bwd_dkv_v2(p, D, dtype, causal, s);
   if (impl == 3) return launch_bwd_dkv_v3(p, dtype, causal, s);
   p.n_tiles = (p.Sk + 127) / 128;

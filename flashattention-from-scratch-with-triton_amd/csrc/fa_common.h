@@ -99,19 +99,20 @@ FA_MFMA_ASM_(mfma_v_f16, "v_mfma_f32_32x32x16_f16")
 // One wave per SIMD owns 256 accumulator registers beside its 256 architectural ones, and everything a VGPR-form asm MFMA
 // touches except its A / B operands must be architectural (C and D share one AGPR bit).  The kernel therefore keeps what
 // does NOT need to be architectural in accumulator registers named LITERALLY in its asm statements:
-//     a[0:63]     the dQ^T accumulators: 4 blocks of 16 (row block, d block), accumulated by asm MFMAs
-//     a[64:127]   the resident B operands: 16 fragments of 4 (Q^T and dO^T k-steps of both row blocks)
-//     a[128:225]  prefetch registers: global loads that land in accumulator registers (a VMEM destination may be an AGPR
-//                 on gfx950) -- the NEXT pass's LSE rows (2) and Q / dO / O fragments (96), fetched during this pass
-//     a[226:255]  hipcc's
+//     dQ (fa_bwd_dq_v4.hip)                                        dK/dV (fa_bwd_dkv_v4.hip)
+//     a[0:63]     dQ^T accumulators: 4 blocks of 16               a[0:127]    dV^T and dK^T accumulators: 8 blocks of 16
+//     a[64:127]   resident B operands: Q^T, dO^T fragments        a[128:191]  resident B operands: K^T, V^T fragments
+//     a[128:129]  LSE rows of the next pass (a global load        a[192:193]  a query tile's row constants (likewise)
+//                 may land in an accumulator register)
+//     a[194:255]  hipcc's
 // Why literal names and not "a" operands: hipcc splits the live range of such an operand where it pleases and copies it back
 // (v_accvgpr_write) right in front of the asm statement, whose MFMA then reads the register inside the write's wait states
 // -- hipcc pads no hazard for an asm statement (seen: a wrong row block in the fp16 causal kernel); and left to allocate the
 // accumulators itself it kept three copies of them for three code regions, 188 v_accvgpr_mov and 112 registers that the
 // prefetch needs.  Registers hipcc never allocates cannot be copied.  What keeps it out: FA_PIN_CLOBBERS on the statements
 // that bracket every long live range (each chain start, the prologue and epilogue statements), and what proves it stayed out:
-// tools/mfma_lint.py rule R4 (a CPU test) reads the code objects and fails on any other instruction that touches a[0:225].
-constexpr int kAccBase = 0, kPinBase = 64, kPfLse = 128, kPfBase = 130, kPinEnd = 226;
+// tools/mfma_lint.py rule R4 (a CPU test) reads the code objects and fails on any other instruction that touches a[0:193].
+constexpr int kAccBase = 0, kPinBase = 64, kPfLse = 128, kPinEnd = 194;
 #define FA_PIN_CLOBBERS \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", \
   "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", \
@@ -129,9 +130,7 @@ constexpr int kAccBase = 0, kPinBase = 64, kPfLse = 128, kPfBase = 130, kPinEnd 
   "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", \
   "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", \
   "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
-  "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", \
-  "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", \
-  "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225"
+  "a192", "a193"
 FA_DEVINL void pin_reserve() { asm volatile("" ::: FA_PIN_CLOBBERS); }
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
 template <int N, typename F>
@@ -144,13 +143,8 @@ FA_DEVINL void static_for(F&& f) {
 // prefetch loads (the caller counts them itself: vmcnt; s_nop 4: a descriptor fresh from a spill lane, see dma16 below) and
 // their read-back
 template <int A>
-FA_DEVINL void pf_load16(__amdgpu_buffer_rsrc_t r, int voff) {
-  static_assert(A >= kPfBase && A + 3 < kPinEnd, "prefetch register range");
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c2:%c3], %0, %1, 0 offen" :: "v"(voff), "s"(r), "i"(A), "i"(A + 3));
-}
-template <int A>
 FA_DEVINL void pf_load4(__amdgpu_buffer_rsrc_t r, int voff) {
-  static_assert(A >= kPfLse && A < kPfBase, "prefetch register range");
+  static_assert(A >= kPfLse && A < kPinEnd, "prefetch register range");
   asm volatile("s_nop 4\n\tbuffer_load_dword a[%c2], %0, %1, 0 offen" :: "v"(voff), "s"(r), "i"(A));
 }
 template <int A>
@@ -170,7 +164,7 @@ FA_DEVINL void acc_write4(u32x4 v) {   // a[A : A + 3]; the caller leaves the wr
                "v_accvgpr_write_b32 a[%c7], %3"
                :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(A), "i"(A + 1), "i"(A + 2), "i"(A + 3));
 }
-template <int F> FA_DEVINL void pin_write(u32x4 v) { static_assert(F >= 0 && F < 16, "16 pinned fragments"); acc_write4<kPinBase + 4 * F>(v); }
+template <int F> FA_DEVINL void pin_write(u32x4 v) { static_assert(F >= 0 && F < 32, "pinned fragments: a[64 + 4F ..], 16 in the dQ kernel, 16..31 in the dK/dV kernel"); acc_write4<kPinBase + 4 * F>(v); }
 template <int F> FA_DEVINL u32x4 pin_read() { return acc_read4<kPinBase + 4 * F>(); }
 // a 16-register accumulator block a[A : A + 15]: zero, read out (after the last MFMA's 12+ wait states: the callers sit behind
 // a barrier)

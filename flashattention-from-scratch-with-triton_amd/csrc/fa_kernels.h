@@ -149,6 +149,8 @@ inline hipError_t opt_in_lds(const void* kern, int bytes, std::atomic<unsigned l
 //             2 = fa_bwd_dkv_v2.hip  128-row Q/dO tiles, hand-ordered pipeline (D = 64, 128)
 //             3 = fa_bwd_dkv_v3.hip  256-key workgroups, ONE wave per SIMD with 64 keys, every Q / dO fragment read from
 //                                    LDS once for both key groups, continuous hand-ordered pipeline (D = 64)
+//             4 = fa_bwd_dkv_v4.hip  family 3's pipeline on the pinned accumulator file: ring of three tiles, counted waits,
+//                                    a barrier-free per-wave diagonal phase with the mask in the chain start (D = 64, fixed length)
 // The table is keyed on (kernel, D, dtype, causal, B*H bucket, S bucket); a family the launch cannot use (strided
 // views for the 64-rows-per-wave kernels, a head dim it does not exist for) falls back to family 1.
 // fa_debug_force_impl() (not in the public header) overrides the table for tests, A/B runs and the tuner; 0 = table.
@@ -187,11 +189,15 @@ inline int pick_dq_impl(int forced, int D, int dtype, int B, int H, int Sq, int 
   if (f == 3 && D != 64) f = 1;
   return (f >= 2 && f <= 4) ? f : 1;
 }
-inline int pick_dkv_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal) {
+inline int pick_dkv_impl(int forced, int D, int dtype, int B, int H, int Sq, int Sk, bool causal, bool fixed_length = true) {
   if (D != 64 && D != 128) return 1;
-  const int f = forced ? forced : table_family(kKernelDkv, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  int f = forced ? forced : table_family(kKernelDkv, D, dtype, causal, (long)B * H, Sq > Sk ? Sq : Sk);
+  // family 4: fixed length, whole 128-row query tiles and 256-key tiles; causal launches only when every key tile has its two
+  // diagonal query tiles (S_q >= S_k) -- its diagonal phase has no ragged path (fa_bwd_dkv_v4.hip); otherwise family 3
+  // (and bf16 only under the causal mask: the fp16 causal instance does not fit the register file)
+  if (f == 4 && (D != 64 || !fixed_length || Sq % 128 != 0 || Sk % 256 != 0 || (causal && (Sq < Sk || dtype != 1)))) f = 3;
   if (f == 3) return D == 64 ? 3 : 2;
-  return f == 2 ? 2 : 1;
+  return f == 4 ? 4 : (f == 2 ? 2 : 1);
 }
 
 // Causal tile pairing equalises the work per workgroup but halves the number of workgroups: worth it as

@@ -12,6 +12,9 @@ import torch  # noqa: E402
 import _mi355fa as host  # noqa: E402
 
 kern, fa_, fb_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+# --reordered-causal: the second family sums the causal query tiles in another order (fa_bwd_dkv_v4.hip): causal results may
+# then differ by fp32 summation order -- at most one unit in the last place of the 16-bit output on a small share of elements
+REORDERED = "--reordered-causal" in sys.argv
 lib = host.lib
 lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
 SHAPES = [(1, 2, 64, 64), (1, 2, 128, 128), (2, 3, 192, 192), (1, 2, 256, 256), (2, 2, 320, 320), (1, 2, 448, 448),
@@ -54,6 +57,15 @@ for dt, code in ((torch.bfloat16, 1), (torch.float16, 0)):
                                    b.view(torch.int16 if b.dtype != torch.float32 else torch.int32))
                        for a, b in zip(outs[0], outs[1]))
             nan = any(torch.isnan(x.float()).any().item() for x in outs[1])
+            if REORDERED and causal and not same and not nan:
+                ok = True
+                for a_, b_ in zip(outs[0], outs[1]):
+                    ne = (a_ != b_)
+                    ulp = (a_.float().abs().clamp_min(1e-30) * (2.0 ** -7 if a_.dtype == torch.bfloat16 else 2.0 ** -10))
+                    # one unit in the last place of the larger magnitude, on at most 2 % of the elements
+                    ok = ok and bool(((a_.float() - b_.float()).abs() <= 1.01 * torch.maximum(ulp, ulp * 0 + 1e-6)).all()) and float(ne.float().mean()) < 0.02
+                if ok:
+                    continue
             if not same or nan:
                 bad += 1
                 d = [(a.float() - b.float()).abs().max().item() for a, b in zip(outs[0], outs[1])]

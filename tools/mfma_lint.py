@@ -18,9 +18,9 @@ instruction = 1, a transcendental or an MFMA = 2, s_nop N = N + 1, an MFMA issue
   R3  nothing but an MFMA reads or writes its D registers earlier than 12 wait states after it
   R5  no spill-lane restore (v_readlane / v_readfirstlane) of a descriptor or scalar offset less than 5 wait states before an
       inline-asm buffer load that reads it (LDS-DMA, prefetch into accumulator registers): a stale descriptor is a memory fault
-  R4  the pinned accumulator file a[0:225] of fa_common.h is touched only by the instructions that own it: accumulators a[0:63]
-      by MFMAs, zeroing v_accvgpr_write_b32 and the epilogue's v_accvgpr_read_b32; resident operands a[64:127] by sets of 64
-      v_accvgpr_write_b32, MFMAs and sets of 32 v_accvgpr_read_b32; prefetch registers a[128:225] by buffer loads and
+  R4  the pinned accumulator file a[0:193] of fa_common.h is touched only by the instructions that own it: accumulators by
+      MFMAs, zeroing v_accvgpr_write_b32 and the epilogue's v_accvgpr_read_b32; resident operands by sets of v_accvgpr_write_b32,
+      MFMAs and (the scaled-Q workspace store) sets of 32 v_accvgpr_read_b32; prefetch registers by buffer_load_dword and
       v_accvgpr_read_b32 -- hipcc never allocates any of them
 
 The model is linear (it follows the instruction stream, not branches): a hazard across a taken branch is not seen.
@@ -117,7 +117,7 @@ def disassemble(elf):
 def lint_kernel(insts):
     bad = []
     # a kernel on the pinned accumulator file issues ALL its MFMAs as inline asm (fa_common.h)
-    all_asm = any(i.is_mfma and len(i.ops) >= 4 and i.ops[0].startswith("v") and regs(i.ops[2]) & {("a", k) for k in range(64, 128)} for i in insts)
+    all_asm = any(i.is_mfma and len(i.ops) >= 4 and i.ops[0].startswith("v") and regs(i.ops[2]) & {("a", k) for k in range(0, 194)} for i in insts)
     for k, m in enumerate(insts):
         if not m.is_mfma or len(m.ops) < 4:
             continue
@@ -168,33 +168,42 @@ def lint_kernel(insts):
                 bad.append("R5 %s %s  <- %s %s (%d wait states before)" % (m.op, ", ".join(m.ops), q.op, ", ".join(q.ops), ws))
             ws += q.ws
             j -= 1
-    # R4: the pinned accumulator file a[0:225] (fa_common.h): accumulators a[0:63], resident B operands a[64:127], prefetch
-    # registers a[128:225].  A kernel uses it iff one of its VGPR-form MFMAs takes its B operand from a[64:127].
-    acc = {("a", i) for i in range(0, 64)}
-    res = {("a", i) for i in range(64, 128)}
-    pf = {("a", i) for i in range(128, 226)}
-    uses = any(i.is_mfma and len(i.ops) >= 4 and i.ops[0].startswith("v") and regs(i.ops[2]) & res for i in insts)
+    # R4: the pinned accumulator file a[0:193] (fa_common.h).  A kernel uses it iff one of its VGPR-form MFMAs takes its B
+    # operand from an accumulator register; the dQ kernel keeps accumulators a[0:63], resident operands a[64:127] and prefetch
+    # registers a[128:129], the dK/dV kernel a[0:127], a[128:191] and a[192:193].
+    pinned = {("a", i) for i in range(0, 194)}
+    uses = [i for i in insts if i.is_mfma and len(i.ops) >= 4 and i.ops[0].startswith("v") and regs(i.ops[2]) & pinned]
     if uses:
+        lo = min(n for i in uses for f, n in regs(i.ops[2]) if f == "a")
+        n_acc, n_res = (64, 64) if lo < 128 else (128, 64)
+        acc = {("a", i) for i in range(0, n_acc)}
+        res = {("a", i) for i in range(n_acc, n_acc + n_res)}
+        pf = {("a", i) for i in range(n_acc + n_res, n_acc + n_res + 2)}
+        rest = pinned - acc - res - pf
+
         def ops_of(sel):
             return sorted({i.op for i in sel})
         wr = [i for i in insts if i.writes & acc and not i.is_mfma]
-        if any(i.op != "v_accvgpr_write_b32" for i in wr) or len(wr) % 64:
-            bad.append("R4 a[0:63] written by %d non-MFMA instructions (%s), expected sets of 64 zeroing v_accvgpr_write_b32" % (len(wr), ops_of(wr)))
+        if any(i.op != "v_accvgpr_write_b32" for i in wr) or len(wr) % n_acc:
+            bad.append("R4 accumulators written by %d non-MFMA instructions (%s), expected sets of %d zeroing v_accvgpr_write_b32" % (len(wr), ops_of(wr), n_acc))
         rd = [i for i in insts if i.reads & acc and not i.is_mfma]
-        if any(i.op != "v_accvgpr_read_b32" for i in rd) or len(rd) % 64:
-            bad.append("R4 a[0:63] read by %d non-MFMA instructions (%s), expected sets of 64 v_accvgpr_read_b32" % (len(rd), ops_of(rd)))
+        if any(i.op != "v_accvgpr_read_b32" for i in rd) or len(rd) % n_acc:
+            bad.append("R4 accumulators read by %d non-MFMA instructions (%s), expected sets of %d v_accvgpr_read_b32" % (len(rd), ops_of(rd), n_acc))
         wr = [i for i in insts if i.writes & res]
-        if not wr or len(wr) % 64 or any(i.op != "v_accvgpr_write_b32" for i in wr):
-            bad.append("R4 a[64:127] written by %d instructions (%s), expected sets of 64 v_accvgpr_write_b32" % (len(wr), ops_of(wr)))
+        if not wr or len(wr) % n_res or any(i.op != "v_accvgpr_write_b32" for i in wr):
+            bad.append("R4 resident operands written by %d instructions (%s), expected sets of %d v_accvgpr_write_b32" % (len(wr), ops_of(wr), n_res))
         rd = [i for i in insts if i.reads & res and not i.is_mfma]
         if len(rd) % 32 or any(i.op != "v_accvgpr_read_b32" for i in rd):
-            bad.append("R4 a[64:127] read by %d non-MFMA instructions (%s)" % (len(rd), ops_of(rd)))
+            bad.append("R4 resident operands read by %d non-MFMA instructions (%s)" % (len(rd), ops_of(rd)))
         wr = [i for i in insts if i.writes & pf]
-        if any(i.op not in ("buffer_load_dwordx4", "buffer_load_dword") for i in wr):
-            bad.append("R4 a[128:225] written by %s, expected the prefetch loads only" % ops_of(wr))
+        if any(i.op != "buffer_load_dword" for i in wr):
+            bad.append("R4 prefetch registers written by %s, expected buffer_load_dword only" % ops_of(wr))
         rd = [i for i in insts if i.reads & pf]
-        if any(i.op != "v_accvgpr_read_b32" for i in rd) or (wr and len(rd) % 2):
-            bad.append("R4 a[128:225] read by %d instructions (%s), expected v_accvgpr_read_b32 only" % (len(rd), ops_of(rd)))
+        if any(i.op != "v_accvgpr_read_b32" for i in rd):
+            bad.append("R4 prefetch registers read by %s, expected v_accvgpr_read_b32 only" % ops_of(rd))
+        other = [i for i in insts if (i.reads | i.writes) & rest]
+        if other:
+            bad.append("R4 %d instructions (%s) touch pinned registers this kernel does not use" % (len(other), ops_of(other)))
     return bad
 
 
