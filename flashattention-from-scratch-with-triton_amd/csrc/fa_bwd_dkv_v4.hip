@@ -43,7 +43,11 @@ struct Dkv4Cfg {
   static constexpr int DO_BASE = NBUF * TILE_BYTES;         // Q[NBUF], then dO[NBUF]
   static constexpr int ROWC_OFF = 2 * NBUF * TILE_BYTES;    // then row constants: nl[BQ], nd[BQ] per slot
   static constexpr int ROWC_BYTES = 2 * BQ * 4;
-  static constexpr int LDS_BYTES = ROWC_OFF + NBUF * ROWC_BYTES;   // 99 KiB
+  // behind them: the NEXT pass's K rows, 64 per wave (key groups w and 7 - w, 32 rows x 128 B each), staged by LDS-DMA; its
+  // V rows are staged in the ring slot that is free when they arrive (the kernel says where)
+  static constexpr int KS_OFF = ROWC_OFF + NBUF * ROWC_BYTES;
+  static constexpr int KG_BYTES = 32 * ROWB;                // one key group's rows: 4 KiB = 4 pieces
+  static constexpr int LDS_BYTES = KS_OFF + BK * ROWB;      // 131 KiB
   static constexpr int PIECES = TILE_BYTES / (NW * 1024);   // 1-KiB LDS-DMA pieces per wave per matrix (4)
   static constexpr int RPI = 1024 / ROWB;                   // tile rows per piece
   static constexpr int NS = 16;                             // MFMA slots per block iteration
@@ -53,8 +57,31 @@ struct Dkv4Cfg {
   static constexpr int ACC_DV = 0, ACC_DK = 64, F_K = 16, F_V = 24, A_RC = 192;
 };
 
+// -DFA_STAMPS (diagnostic build, tools/stamps_dq4.py --dkv): per-phase cycle account of a wave, written to BwdParams::dbg.
+// seg[0] pass prologue (ring primed, K / V fragments, first barrier, fill)   seg[1] unmasked tiles   seg[2] diagonal phase
+// seg[3] drain   seg[4] epilogue
+#ifdef FA_STAMPS
+#define FA4K_STAMP(slot)                                                          \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long now_;                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += now_ - last_;                                                    \
+    last_ = now_;                                                                 \
+  } while (0)
+#else
+#define FA4K_STAMP(slot) do {} while (0)
+#endif
+
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
+#ifdef FA_STAMPS
+  unsigned long long clk0_, rt0_;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = clk0_, ntile_ = 0, npass_ = 0;
+#endif
   using C = Dkv4Cfg;
   using vec8 = typename T::vec8;
   constexpr int D = C::D;
@@ -65,33 +92,75 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  // Work list: one item = one 256-key tile, or (causal, paired) the tile pair (i, nk-1-i) -> equal work per item; the
+  // XCD-aware order gives every XCD a contiguous run of (batch, head) slices.  Causal launches are PERSISTENT (one workgroup
+  // per CU walks items blockIdx.x, blockIdx.x + gridDim.x, ...): a pass's resident K / V rows are staged through LDS from
+  // inside the PREVIOUS pass (below), and an item's first pass has no previous pass unless the workgroup stays.
   const bool paired = CAUSAL && p.pair;
   const int nk = p.n_tiles;
   const int per_bh = paired ? (nk + 1) / 2 : nk;
-  const int bh = w / per_bh;
-  const int idx = w - bh * per_bh;
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int n_items = per_bh * p.B * p.H;
   const int Sq = p.Sq, Sk = p.Sk;
-  const int npass = (paired && idx != nk - 1 - idx) ? 2 : 1;
-
-  // (descriptors are built where they are used: 106 scalar registers do not hold seven of them across the tile loop)
-  const int q_rs = p.lq.rs, do_rs = p.ldo.rs;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
-  // row constants of a query tile: threads 0-127 load its LSE rows, 128-255 its delta rows, through ONE wave-uniform
-  // descriptor (waves 0-1 / 2-3)
-  const bool rc_lse = wave < 2;
-  const __amdgpu_buffer_rsrc_t rrc = make_rsrc((rc_lse ? p.lse : p.delta) + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
+  const int q_rs = p.lq.rs, do_rs = p.ldo.rs, kv_rs = p.lk.rs;
   const float c2 = p.scale * kLog2e;
   const int lds0 = (int)lds_addr_of(smem);
   const int ntiles = Sq / C::BQ;   // the launcher guarantees whole tiles
+  // row constants of a query tile: threads 0-127 load its LSE rows, 128-255 its delta rows, through ONE wave-uniform
+  // descriptor (waves 0-1 / 2-3)
+  const bool rc_lse = wave < 2;
   pin_reserve();
+
+  struct Work {
+    int b, h, idx, npass;
+  };
+  auto decode = [&](int item) __attribute__((always_inline)) -> Work {
+    const int w = xcd_remap(item, n_items);
+    const int bh = w / per_bh, idx = w - bh * per_bh, b = bh / p.H;
+    return Work{b, bh - b * p.H, idx, (paired && idx != nk - 1 - idx) ? 2 : 1};
+  };
+  auto ktile_of = [&](const Work& wk, int pass) __attribute__((always_inline)) -> int {   // low key tiles are the heavy ones
+    return paired ? (pass == 0 ? wk.idx : nk - 1 - wk.idx) : wk.idx;
+  };
+  // The resident operands of a pass -- the K and V rows of this wave's two key groups -- are STAGED through LDS a whole phase
+  // before the pass needs them (fa_bwd_dq_v4.hip says why: fetched as per-lane fragments they cost a wave thousands of cycles
+  // of address-unit time at the top of a pass, with nothing else on the CU to cover them).  Four groups of four LDS-DMA pieces
+  // per wave: g = 0, 1 K rows of key group 0, 1 -> KS; 2 V rows of key group 0 -> this wave's rows of the Q half of ring slot
+  // `vslot`, 3 V rows of key group 1 -> its rows of the dO half: exactly the 2 x 4 KiB this wave fills itself with the pass's
+  // third tile, once it has consumed them -- no other wave ever touches them.
+  struct Stage {
+    __amdgpu_buffer_rsrc_t rk, rv;
+    int key0[2];
+  };
+  auto stage_of = [&](const Work& wk, int pass, bool valid) __attribute__((always_inline)) -> Stage {
+    const int k0 = ktile_of(wk, pass) * C::BK;
+    const unsigned nb = valid ? view_bytes(Sk, kv_rs, C::ROWB) : 0u;   // nothing follows: empty descriptors fetch nothing
+    return Stage{make_rsrc((const char*)p.k + wk.b * p.lk.sb + wk.h * p.lk.sh, nb),
+                 make_rsrc((const char*)p.v + wk.b * p.lv.sb + wk.h * p.lv.sh, nb), {k0 + 32 * wave, k0 + 32 * (7 - wave)}};
+  };
+  auto stage_group = [&](const Stage& st, int vslot, int g) __attribute__((always_inline)) {
+    const int ln = lane_id_now(), prow = ln >> 3;   // piece i holds rows 8 i + prow of the key group
+    const int kg = g & 1;
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // (dma_pieces: the immediate 1024 i moves LDS and global address together: taken out here)
+      voff[i] = (st.key0[kg] + 8 * i + prow) * kv_rs + swz_chunk<D>(8 * i + prow, ln & 7) * 16 - 1024 * i;
+    const int dst = g < 2 ? C::KS_OFF + (2 * wave + kg) * C::KG_BYTES : (kg ? C::DO_BASE : 0) + vslot * C::TILE_BYTES + wave * C::KG_BYTES;
+    dma_pieces<4>(g < 2 ? st.rk : st.rv, (unsigned)(lds0 + dst), voff, 0);
+  };
+
+  int item = blockIdx.x;
+  Work wk = decode(item);
+  int b0 = 0, b1 = 1, b2 = 2;   // ring slots of stream positions i, i + 1, i + 2; they keep rotating from pass to pass
+  bool staged = false;          // this pass's rows are on their way (issued from inside the previous pass)
+  for (; item < n_items; item += gridDim.x, wk = decode(min(item, n_items - 1))) {
+  const int b_ = wk.b, h_ = wk.h, npass = wk.npass;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
+  const __amdgpu_buffer_rsrc_t rrc = make_rsrc((rc_lse ? p.lse : p.delta) + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
 
   for (int pass = 0; pass < npass; ++pass) {
     const int lane = lane_id_now(), r = lane & 31, h = lane >> 5;
-    const int kt_idx = paired ? (pass == 0 ? idx : nk - 1 - idx) : idx;  // low key tiles are the heavy ones
-    const int k0_wg = kt_idx * C::BK;
+    const int k0_wg = ktile_of(wk, pass) * C::BK;
     // this wave's two 32-key groups: {w, 7-w} of the workgroup's eight (equal causal work per wave, see the header)
     const int kw[2] = {k0_wg + 32 * wave, k0_wg + 32 * (7 - wave)};
     // The pass's tile STREAM: position i = query tile t0 + 2 + i for the n_main unmasked tiles, then (causal) the two tiles
@@ -137,43 +206,39 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
     using RC0 = std::integral_constant<int, C::A_RC>;
     using RC1 = std::integral_constant<int, C::A_RC + 1>;
 
-    // ---- the ring: stream positions 0 and 1 whole, the first half of 2; then the resident operands ----
-    int b0 = 0, b1 = 1, b2 = 2;   // ring slots of stream positions i, i + 1, i + 2
+    // ---- the staged K / V rows; the ring: stream positions 0 and 1 whole, the first half of 2 once V is consumed ----
+    if (!staged) {   // the first pass of a workgroup (and every pass of a non-causal launch): nothing to hide behind
+      const Stage st = stage_of(wk, pass, true);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) stage_group(st, b2, g);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      // everything but the previous pass's 16 epilogue stores, which are younger and not worth waiting for
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) dma_group(0, b0, g4);
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) dma_group(1, b1, g4);
-    dma_group(2, b2, 0);
-    dma_group(2, b2, 1);
     rc_request(RC0{}, 0);
-    // resident B operands: K^T and V^T fragments of this wave's two key groups, pinned (fa_common.h)
-    {
-      const int kv_rs = p.lk.rs;
-      const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, view_bytes(Sk, kv_rs, C::ROWB));
-      const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, view_bytes(Sk, kv_rs, C::ROWB));
-      u32x4 kraw[2][C::KS], vraw[2][C::KS];
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          const int off = (kw[g] + r) * kv_rs + (2 * ks + h) * 16;
-          kraw[g][ks] = buf_load16(rk, off);
-          vraw[g][ks] = buf_load16(rv, off);
-        }
-      static_for<2 * C::KS>([&](auto i_) __attribute__((always_inline)) {
-        constexpr int i = decltype(i_)::value, g = i / C::KS, ks = i % C::KS;
-        vec8 kk = as_vec8<T>(kraw[g][ks]);
-        if (FOLD && !p.q_prescaled) kk = scale_frag<T>(kk, c2);  // K * softmax_scale * log2(e)
-        pin_write<C::F_K + 4 * g + ks>(__builtin_bit_cast(u32x4, kk));
-        pin_write<C::F_V + 4 * g + ks>(vraw[g][ks]);
-      });
-    }
-    static_for<8>([](auto i_) __attribute__((always_inline)) { acc_zero16<16 * decltype(i_)::value>(); });
-
-    // ---- loop-invariant per-lane LDS offsets ----
     int row_off[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
+    // resident B operands: K^T and V^T fragments of this wave's two key groups (row reads of the staged rows), pinned
+    static_for<2 * C::KS>([&](auto i_) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_)::value, g = i / C::KS, ks = i % C::KS;
+      vec8 kk = as_vec8<T>(lds_read16(smem + C::KS_OFF + (2 * wave + g) * C::KG_BYTES + row_off[ks]));
+      if (FOLD && !p.q_prescaled) kk = scale_frag<T>(kk, c2);  // K * softmax_scale * log2(e)
+      pin_write<C::F_K + 4 * g + ks>(__builtin_bit_cast(u32x4, kk));
+      pin_write<C::F_V + 4 * g + ks>(lds_read16(smem + (g ? C::DO_BASE : 0) + b2 * C::TILE_BYTES + wave * C::KG_BYTES + row_off[ks]));
+    });
+    // the V rows are consumed (every read above has fed a register write): this wave's part of slot b2 takes position 2
+    __builtin_amdgcn_sched_barrier(0);
+    dma_group(2, b2, 0);
+    dma_group(2, b2, 1);
+    static_for<8>([](auto i_) __attribute__((always_inline)) { acc_zero16<16 * decltype(i_)::value>(); });
+
+    // ---- loop-invariant per-lane LDS offsets ----
     int tr_off[2][C::DB];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -383,8 +448,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
     pipe_fill(I1{}, 1);
     __builtin_amdgcn_sched_barrier(0);
 
+    FA4K_STAMP(0);
     // ---- the unmasked tiles: eight block iterations per tile, ring slots rotate ----
     for (int i = 0; i < n_main; ++i) {
+#ifdef FA_STAMPS
+      ++ntile_;
+#endif
       int tA[2][C::DB], kq[C::KS], kN[C::KS];
       tr_bases(tA, b0 * C::TILE_BYTES);
       row_bases(kq, b0 * C::TILE_BYTES);
@@ -425,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       b2 = bt;
     }
 
+    FA4K_STAMP(1);
     if constexpr (!CAUSAL) {
       pipe_drain(I1{}, I1{}, I1{});
     } else {
@@ -452,6 +522,23 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       // (only instantiated where the scale is folded -- bf16: the query-block parity, which selects the fp16 path's NL set,
       // plays no part, and every block below passes parity 0)
       static_assert(FOLD, "the causal instance exists for the folded-scale dtype only (launch_bwd_dkv_v4)");
+      // No vmcnt wait from here to the end of the pass and ring slot b2 is free: the place to stage the NEXT pass's K / V rows
+      // (the pair's second pass, or the first pass of the workgroup's next item).  The four piece groups ride in the three
+      // block iterations below that every wave executes exactly once; with nothing to follow the descriptors are empty.
+      const bool more_pass = pass + 1 < npass, more_item = item + (int)gridDim.x < n_items;
+      const Stage nst = stage_of(more_pass ? wk : decode(min(item + (int)gridDim.x, n_items - 1)), more_pass ? pass + 1 : 0,
+                                 more_pass || more_item);
+      auto hook_a = [&](int s, int phase) __attribute__((always_inline)) {
+        if (phase == 1 && s == 2) stage_group(nst, b2, 0);
+        if (phase == 1 && s == 10) stage_group(nst, b2, 1);
+      };
+      auto hook_b = [&](int s, int phase) __attribute__((always_inline)) {
+        if (phase == 1 && s == 6) stage_group(nst, b2, 2);
+      };
+      auto hook_c = [&](int s, int phase) __attribute__((always_inline)) {
+        if (phase == 1 && s == 4) stage_group(nst, b2, 3);
+      };
+      staged = more_pass || more_item;
       int trb[2][C::DB], nxt[C::KS];
       // the last unmasked iteration prefetched the fragments of the block that FOLLOWS in memory; the phase starts at block 7
       load_block(qbase(7), rcaddr(7) - lds0 - 16 * h, 1);
@@ -467,37 +554,42 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       // q = 7 - wave
       tr_bases(trb, qbase(q));
       row_bases(nxt, qbase(max(q - 1, 0)));
-      block_iter(I0{}, I0{}, I1{}, I0{}, No{}, No{}, No{}, trb, 0, nxt, 0, 0, no_hook);
+      block_iter(I0{}, I0{}, I1{}, I0{}, No{}, No{}, No{}, trb, 0, nxt, 0, 0, hook_a);
       diag_start(q);
-      block_iter(I1{}, I1{}, I0{}, I0{}, No{}, Yes{}, Yes{}, trb, 0, nxt, 0, rcaddr(max(q - 1, 0)), no_hook);
+      block_iter(I1{}, I1{}, I0{}, I0{}, No{}, Yes{}, Yes{}, trb, 0, nxt, 0, rcaddr(max(q - 1, 0)), hook_b);
       // key group 0 (group `wave`) alone: query blocks 6 - wave .. wave (an odd number: sets 0, 1, .., 0), the last on its
       // diagonal.  The first solo follows the pair's second iteration (key group 1), the others follow a solo (key group 0).
       // (offsets evaluated by the caller: a lambda that captures the qbase / rcaddr closures puts the ring slots they refer to
       // into memory, and hipcc then reads b0 / b1 back from scratch as per-lane values)
-      auto solo = [&](auto g_tag, auto pkg_tag, auto next_tag, auto diag_tag, int off, int off_next, int rc_next) __attribute__((always_inline)) {
+      auto solo = [&](auto g_tag, auto pkg_tag, auto next_tag, auto diag_tag, int off, int off_next, int rc_next, auto&& hook) __attribute__((always_inline)) {
         tr_bases(trb, off);
         if constexpr (decltype(next_tag)::value) row_bases(nxt, off_next);
         if constexpr (decltype(diag_tag)::value) diag_start(0);
-        block_iter(g_tag, I0{}, pkg_tag, I0{}, Yes{}, next_tag, diag_tag, trb, 0, nxt, 0, rc_next, no_hook);
+        block_iter(g_tag, I0{}, pkg_tag, I0{}, Yes{}, next_tag, diag_tag, trb, 0, nxt, 0, rc_next, hook);
       };
       if (6 - wave <= wave) {   // wave 3: its only solo
-        solo(I0{}, I1{}, No{}, Yes{}, qbase(wave), 0, 0);
+        solo(I0{}, I1{}, No{}, Yes{}, qbase(wave), 0, 0, hook_c);
       } else {
         q = 6 - wave;
-        solo(I0{}, I1{}, Yes{}, No{}, qbase(q), qbase(q - 1), rcaddr(q - 1));
+        solo(I0{}, I1{}, Yes{}, No{}, qbase(q), qbase(q - 1), rcaddr(q - 1), no_hook);
         for (q = 5 - wave; q > wave + 1; q -= 2) {
-          solo(I1{}, I0{}, Yes{}, No{}, qbase(q), qbase(q - 1), rcaddr(q - 1));
-          solo(I0{}, I0{}, Yes{}, No{}, qbase(q - 1), qbase(q - 2), rcaddr(q - 2));
+          solo(I1{}, I0{}, Yes{}, No{}, qbase(q), qbase(q - 1), rcaddr(q - 1), no_hook);
+          solo(I0{}, I0{}, Yes{}, No{}, qbase(q - 1), qbase(q - 2), rcaddr(q - 2), no_hook);
         }
-        solo(I1{}, I0{}, Yes{}, No{}, qbase(wave + 1), qbase(wave), rcaddr(wave));
-        solo(I0{}, I0{}, No{}, Yes{}, qbase(wave), 0, 0);
+        solo(I1{}, I0{}, Yes{}, No{}, qbase(wave + 1), qbase(wave), rcaddr(wave), no_hook);
+        solo(I0{}, I0{}, No{}, Yes{}, qbase(wave), 0, 0, hook_c);
       }
+      FA4K_STAMP(2);
       pipe_drain(I0{}, I0{}, I0{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (out-of-range) fetches past the last tile are over
+    FA4K_STAMP(3);
+    // non-causal: the (out-of-range) fetches past the last tile are over before the ring is reused (causal: they were, at
+    // the start of the diagonal phase -- what is in flight now are the NEXT pass's staged rows, which land outside the staging area)
+    if constexpr (!CAUSAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     __syncthreads();  // every wave is done with the tile buffers: they become the staging area
-    FA_LDS char* stage = smem + wave * 32 * C::ROWB;
+    // staged in this wave's rows of the Q half of slot b0 (dead since the barrier above; the wave's own next fetch goes there)
+    FA_LDS char* stage = smem + b0 * C::TILE_BYTES + wave * C::KG_BYTES;
     // dK = dS^T Q * scale; with the pre-scaled Q (= Q * scale * log2e) in LDS that is dS^T Q' * ln 2
     const float dk_mul = (FOLD && p.q_prescaled) ? kLn2 : p.scale;
     {
@@ -513,14 +605,41 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       const f32x16 dv1[C::DB] = {acc_read16<C::ACC_DV + 32>(), acc_read16<C::ACC_DV + 48>()};
       store_tile_rows<D, T>(dv1, 1.0f, stage, rdv, kw[1] * dv_rs, lane, dv_rs);
     }
-    __syncthreads();  // the staging area is the next pass's ring again
+    FA4K_STAMP(4);
+#ifdef FA_STAMPS
+    ++npass_;
+#endif
   }  // pass
+  }  // item
+#ifdef FA_STAMPS
+  if (p.dbg && (threadIdx.x & 63) == 0) {
+    unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 32;
+    for (int i = 0; i < 8; ++i) d[i] = seg[i];
+    d[17] = ntile_;
+    unsigned long long clk1_, rt1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_), "=s"(rt1_)::"memory");
+    d[18] = clk1_ - clk0_;
+    d[19] = rt1_ - rt0_;
+    d[20] = npass_;
+  }
+#endif
 }
 
 template <typename T, bool CAUSAL>
 static hipError_t launch4(const BwdParams& p, hipStream_t s) {
   using C = Dkv4Cfg;
-  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  if (CAUSAL) {   // persistent: one workgroup per CU walks the work list (a multiple of 8 keeps a workgroup on one XCD's items)
+    static std::atomic<int> cus{0};   // CU count of the device first launched on (devices of one node are alike)
+    int n = cus.load(std::memory_order_relaxed);
+    if (n == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+      n -= n % 8;
+      cus.store(n, std::memory_order_relaxed);
+    }
+    if (grid > n) grid = n;
+  }
   auto kern = fa_bwd_dkv4_kernel<T, CAUSAL>;
   static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
   if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES, opted_in)) return e;

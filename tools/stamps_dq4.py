@@ -13,6 +13,7 @@ for name, (res, args) in host.SIGNATURES.items():
 lib.fa_debug_set_buffer.argtypes = [ctypes.c_void_p]
 lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
 causal = "--non-causal" not in sys.argv
+DKV = "--dkv" in sys.argv   # the family-4 dK/dV kernel (same record layout, five phases)
 B, H, S, D = 4, 32, 4096, 64
 torch.manual_seed(0)
 Q, K, V, dO = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(4))
@@ -21,8 +22,11 @@ dQ, delta = torch.empty_like(Q), torch.empty_like(LSE)
 st = torch.cuda.current_stream().cuda_stream
 P = lambda t: t.data_ptr()
 c, sc = int(causal), D ** -0.5
-lib.fa_debug_force_impl(1, 4, 0)
+lib.fa_debug_force_impl(1, 1 if DKV else 4, 4)
 lib.fa_fwd(P(Q), P(K), P(V), P(O), P(LSE), B, H, S, S, D, 1, c, sc, st)
+dK, dV = torch.empty_like(K), torch.empty_like(V)
+if DKV:
+    lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, 1, c, sc, st)
 nqt = S // 256
 nwg = (nqt // 2 if causal else nqt) * B * H
 dbg = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device="cuda")
@@ -30,7 +34,10 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 for i in range(12):
     lib.fa_debug_set_buffer(dbg.data_ptr())
     if i == 11: e0.record()
-    assert lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, 1, c, sc, st) == 0
+    if DKV:
+        assert lib.fa_bwd_dkv(P(Q), P(K), P(V), P(dO), P(LSE), P(delta), P(dK), P(dV), B, H, S, S, D, 1, c, sc, st) == 0
+    else:
+        assert lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dQ), P(delta), B, H, S, S, D, 1, c, sc, st) == 0
     if i == 11: e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
