@@ -47,7 +47,9 @@ struct Dkv4Cfg {
   // V rows are staged in the ring slot that is free when they arrive (the kernel says where)
   static constexpr int KS_OFF = ROWC_OFF + NBUF * ROWC_BYTES;
   static constexpr int KG_BYTES = 32 * ROWB;                // one key group's rows: 4 KiB = 4 pieces
-  static constexpr int LDS_BYTES = KS_OFF + BK * ROWB;      // 131 KiB
+  // and the epilogue's own staging area (4 KiB per wave): the ring then belongs to the next pass while dK / dV are written out
+  static constexpr int EPI_OFF = KS_OFF + BK * ROWB;
+  static constexpr int LDS_BYTES = EPI_OFF + NW * KG_BYTES;   // 147 KiB
   static constexpr int PIECES = TILE_BYTES / (NW * 1024);   // 1-KiB LDS-DMA pieces per wave per matrix (4)
   static constexpr int RPI = 1024 / ROWB;                   // tile rows per piece
   static constexpr int NS = 16;                             // MFMA slots per block iteration
@@ -183,21 +185,22 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
     }
     // group g4: 0, 1 = the Q pairs, 2, 3 = the dO pairs of this wave's share of tile t (ring slot `buf`); a tile past the
     // last one is out of range for the descriptor (no branch: hipcc sinks code across branches, fa_bwd_dkv_v3.hip)
-    auto dma_group = [&](int pos, int buf, int g4) __attribute__((always_inline)) {
-      const int t = tile_at(pos), i = 2 * (g4 & 1);
+    auto dma_tile = [&](__amdgpu_buffer_rsrc_t rq_, __amdgpu_buffer_rsrc_t rdo_, int t, int buf, int g4) __attribute__((always_inline)) {
+      const int i = 2 * (g4 & 1);
       const int dst = buf * C::TILE_BYTES + ((C::BQ / C::NW) * wave + C::RPI * i) * C::ROWB;
       const int sq = t >= 0 ? t * C::BQ * q_rs : C::kOOB, sd = t >= 0 ? t * C::BQ * do_rs : C::kOOB;
-      if (g4 < 2) dma_pieces<2>(rq, (unsigned)(lds0 + dst), dma_q + i, sq);
-      else dma_pieces<2>(rdo, (unsigned)(lds0 + C::DO_BASE + dst), dma_do + i, sd);
+      if (g4 < 2) dma_pieces<2>(rq_, (unsigned)(lds0 + dst), dma_q + i, sq);
+      else dma_pieces<2>(rdo_, (unsigned)(lds0 + C::DO_BASE + dst), dma_do + i, sd);
     };
+    auto dma_group = [&](int pos, int buf, int g4) __attribute__((always_inline)) { dma_tile(rq, rdo, tile_at(pos), buf, g4); };
     // the row constant of this thread for tile t: requested into a[192] (nothing architectural waits for it), read back and
     // published -- scaled, negated; rows past S_q cannot occur (whole tiles) -- by the commit that makes tile t current
-    auto rc_request = [&](auto a_tag, int pos) __attribute__((always_inline)) {
-      const int t = tile_at(pos);
+    auto rc_tile = [&](__amdgpu_buffer_rsrc_t rrc_, auto a_tag, int t) __attribute__((always_inline)) {
       int x;
       asm volatile("v_and_b32 %0, %1, %2" : "=v"(x) : "n"(C::BQ - 1), "v"(tid));   // row of the tile, re-derived (nothing kept live)
-      pf_load4<decltype(a_tag)::value>(rrc, t >= 0 ? (t * C::BQ + x) * 4 : C::kOOB);
+      pf_load4<decltype(a_tag)::value>(rrc_, t >= 0 ? (t * C::BQ + x) * 4 : C::kOOB);
     };
+    auto rc_request = [&](auto a_tag, int pos) __attribute__((always_inline)) { rc_tile(rrc, a_tag, tile_at(pos)); };
     auto rc_publish = [&](auto a_tag, int buf) __attribute__((always_inline)) {
       const float v = acc_read1<decltype(a_tag)::value>();
       FA_LDS float* rcp = (FA_LDS float*)(smem + C::ROWC_OFF + buf * C::ROWC_BYTES);
@@ -212,15 +215,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) stage_group(st, b2, g);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) dma_group(0, b0, g4);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) dma_group(1, b1, g4);
+      rc_request(RC0{}, 0);
     } else {
-      // everything but the previous pass's 16 epilogue stores, which are younger and not worth waiting for
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      // staged from inside the previous pass, and behind them -- requested in front of its epilogue -- this pass's first two
+      // tiles and first row constant (17 requests), then the epilogue's 16 stores: the staged rows have landed
+      asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
     }
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) dma_group(0, b0, g4);
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) dma_group(1, b1, g4);
-    rc_request(RC0{}, 0);
     int row_off[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) row_off[ks] = lds_off<D>(r, 2 * ks + h);
@@ -435,8 +439,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       for (int n = 0; n < 8; ++n) TF[n] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
     };
 
-    // ---- stream position 0 is current: everything fetched so far has landed ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- stream position 0 is current: everything but the four pieces of position 2 requested last has landed ----
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     rc_publish(RC0{}, b0);
     rc_request(RC0{}, 1);   // the steady state keeps ONE row-constant request in flight, in a[192]
     asm volatile("s_nop 4");  // v_accvgpr_write -> MFMA operand wait states (hipcc pads nothing around asm)
@@ -588,8 +592,24 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
     if constexpr (!CAUSAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     __syncthreads();  // every wave is done with the tile buffers: they become the staging area
-    // staged in this wave's rows of the Q half of slot b0 (dead since the barrier above; the wave's own next fetch goes there)
-    FA_LDS char* stage = smem + b0 * C::TILE_BYTES + wave * C::KG_BYTES;
+    if constexpr (CAUSAL) {
+      if (staged) {   // something follows: its first two tiles and its first row constant are requested NOW -- the ring is free
+                      // since the barrier above -- and land while dK / dV are written out
+        const bool more_pass = pass + 1 < npass;
+        const Work nw = more_pass ? wk : decode(item + (int)gridDim.x);
+        const int t0n = ktile_of(nw, more_pass ? pass + 1 : 0) * C::BK / C::BQ, n_mainn = ntiles - t0n - 2;
+        const int tn0 = n_mainn > 0 ? t0n + 2 : t0n, tn1 = n_mainn > 1 ? t0n + 3 : (n_mainn == 1 ? t0n : t0n + 1);
+        const __amdgpu_buffer_rsrc_t nrq = make_rsrc((const char*)p.q + nw.b * p.lq.sb + nw.h * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
+        const __amdgpu_buffer_rsrc_t nrdo = make_rsrc((const char*)p.dout + nw.b * p.ldo.sb + nw.h * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
+        const __amdgpu_buffer_rsrc_t nrrc = make_rsrc((rc_lse ? p.lse : p.delta) + nw.b * p.lse_sb + nw.h * p.lse_sh, (unsigned)Sq * 4);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dma_tile(nrq, nrdo, tn0, b0, g4);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dma_tile(nrq, nrdo, tn1, b1, g4);
+        rc_tile(nrrc, RC0{}, tn0);
+      }
+    }
+    FA_LDS char* stage = smem + C::EPI_OFF + wave * C::KG_BYTES;
     // dK = dS^T Q * scale; with the pre-scaled Q (= Q * scale * log2e) in LDS that is dS^T Q' * ln 2
     const float dk_mul = (FOLD && p.q_prescaled) ? kLn2 : p.scale;
     {
