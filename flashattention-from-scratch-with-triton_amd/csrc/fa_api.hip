@@ -117,11 +117,8 @@ int fa_debug_pick(int kernel, int D, int dtype, int causal, int B, int H, int S_
   return fa::pick_dkv_impl(fa::g_force_dkv, D, dtype, B, H, S_q, S_k, causal != 0);
 }
 
-// Not part of the public header (tests): passes of the family-4 forward that took their exact second attempt so far.
-// Synchronises the device.
-unsigned fa_debug_fwd4_redo_count(void) { return fa::fwd4_redo_count(); }
-
-// Not part of the public header: diagnostic hook used by tools/stamps.py with -DFA_STAMPS builds.
+// Not part of the public header: diagnostic hook used by tools/stamps*.py with -DFA_STAMPS builds; in the product library the
+// family-4 forward counts, in the buffer's first word, the passes that took their exact second attempt (tests).
 void fa_debug_set_buffer(void* p) { g_dbg = p; }
 
 const char* fa_last_error(void) { return g_err; }

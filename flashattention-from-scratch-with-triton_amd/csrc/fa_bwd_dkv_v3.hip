@@ -24,8 +24,9 @@
 //   current tile's buffer and before the first read of the next one: two LDS buffers, no pipeline bubble.
 //
 // Causal: a workgroup takes the key-tile pair (i, nk-1-i).  A wave owns key groups {w, 7-w} of the 256 keys, so that the
-// diagonal region (the 256 query rows level with the key tile) costs every wave the same 9 of 16 block visits; those two
-// tiles run block by block on a simple compiler-scheduled path, everything below the diagonal in the pipeline.
+// diagonal region (the 256 query rows level with the key tile) holds the same 9 visible of 16 block visits for every wave;
+// those two tiles (and one more) run through the SAME pipeline with a one-compare mask per element -- all 16 visits, the
+// invisible ones masked away (family 4, fa_bwd_dkv_v4.hip, visits only the 9).
 #include <stdlib.h>
 
 #include <type_traits>

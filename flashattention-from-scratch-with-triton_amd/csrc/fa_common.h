@@ -63,7 +63,8 @@ struct FP16 {
   template <typename A4> static FA_DEVINL void mfma_v_acc(f32x16& d, u32x4 a, A4 b);
 };
 
-// MFMA with the accumulator pinned to ARCHITECTURAL VGPRs and the B operand to accumulator registers (inline asm).
+// MFMA with the accumulator pinned to ARCHITECTURAL VGPRs (inline asm); the B operand sits in VGPRs too unless
+// FA_MFMA_B_AGPR is set (an A/B hook, OFF: hipcc then copies the operand back in front of every use).
 // hipcc picks ONE register form for every MFMA builtin of a kernel: once a kernel needs AGPRs (one wave per SIMD, > 256
 // registers) all its MFMA results land in AGPRs, and a result that VALU code consumes (scores -> exp) is then copied out
 // element by element with v_accvgpr_read (measured: 2.6 extra vector instructions per MFMA in fa_bwd_dkv_v3.hip).  These
@@ -71,8 +72,8 @@ struct FP16 {
 // What hipcc does not do for them (no hazard padding inside / after an asm statement): the caller guarantees that
 //   * nothing reads or overwrites D within 12 wait states of the statement except the next MFMA of the same chain
 //     (the accumulate chain itself needs none) -- the pipelines that use this consume D one block iteration later;
-//   * A / C come from LDS reads or older VALU results (hipcc still inserts the s_waitcnt for loads it issued itself) and
-//     B was written by to_agpr() long before (an explicit s_nop follows those writes).
+//   * A / B / C come from LDS reads or older VALU results (hipcc still inserts the s_waitcnt for loads it issued itself).
+// tools/mfma_lint.py checks both on the built code objects (a CPU test).
 typedef __attribute__((ext_vector_type(4))) unsigned agpr4_t;   // a 128-bit fragment living in a[N:N+3]
 #ifndef FA_MFMA_B_AGPR
 #define FA_MFMA_B_AGPR 0   // 1: the B operand of the mfma_v_* forms must live in AGPRs, 0: in VGPRs
@@ -398,15 +399,9 @@ FA_DEVINL void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
 }
 
 // A sequence with queries but no keys (only a variable-length launch can present one; the fixed-length ABI rejects
-// S_k = 0): there is nothing to attend to.  The forward defines O = 0 and LSE = -inf for its rows, the backward dQ = 0
-// and delta = 0 -- the workgroup zero-fills its `nrows` output rows from `row0` on (rows past the descriptor's range are
-// dropped) and issues no K / V access at all (a descriptor sized (S_k - 1) * stride + row would wrap to ~4 GiB).
-template <int D>
-FA_DEVINL void zero_fill_rows(__amdgpu_buffer_rsrc_t dst, int row0, int nrows, int rs, int tid, int nthreads) {
-  constexpr int CPR = D / 8;
-  const u32x4 z = {0u, 0u, 0u, 0u};
-  for (int i = tid; i < nrows * CPR; i += nthreads) buf_store16(dst, (row0 + i / CPR) * rs + (i % CPR) * 16, z);
-}
+// S_k = 0) has nothing to attend to: the forward defines O = 0 and LSE = -inf for its rows, the backward dQ = 0 and delta = 0.
+// No special path: its K / V descriptors have size 0 (view_bytes below), so every K / V access is out of range -- loads
+// return 0, LDS-DMA fetches nothing -- and the kernels' normalisation treats an empty row sum as 0.
 // byte size of a K / V view of `rows` rows for its buffer descriptor (0 rows -> 0 bytes: every access is out of range)
 // (min / max instead of a select: hipcc lowers the select to v_cndmask, which would put the descriptor word in a VGPR)
 FA_DEVINL unsigned view_bytes(int rows, int rs, int rowb) {

@@ -210,7 +210,6 @@ inline int want_pairs(bool, long, long) { return 0; }
 #endif
 
 hipError_t launch_fwd(FwdParams p, int D, int dtype, int causal, hipStream_t s);
-unsigned fwd4_redo_count();   // fa_fwd_v4.hip (tests)
 hipError_t launch_bwd_dq(BwdParams p, int D, int dtype, int causal, hipStream_t s);
 hipError_t launch_bwd_dkv(BwdParams p, int D, int dtype, int causal, hipStream_t s);
 

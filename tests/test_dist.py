@@ -188,3 +188,50 @@ def test_two_rank_code_path_on_one_gpu_matches_the_single_rank_union():
     assert two["config"]["parallelism"] == "batch-sharded x2, no collective"
     assert abs(two["checksum"] - one["checksum"]) <= 1e-6 * abs(one["checksum"])
     assert two["value"] > 0 and two["ms_per_step"] > 0
+
+
+def test_nccl_branch_builds_the_right_arguments_with_a_mocked_process_group(monkeypatch):
+    """the nccl (= RCCL) branch of the harness has never run -- the pool gives one-GPU boxes and the
+    driver's 8-GPU node is the first to execute it.  With torch.distributed and torch.cuda mocked, check what it WOULD pass:
+    the device is selected from LOCAL_RANK before init_process_group, device_id names that device, rendezvous defaults to
+    127.0.0.1, and the scalars of the max / sum reduces live on that device for nccl (on the CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    import _scaling as S
+    calls = {}
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.setdefault("set_device", d))
+    state = {"init": False}
+    monkeypatch.setattr(dist, "is_initialized", lambda: state["init"])
+
+    def fake_init(**kw):
+        assert "set_device" in calls, "the device must be selected before the process group is created"
+        calls["init"] = kw
+        state["init"] = True
+    monkeypatch.setattr(dist, "init_process_group", fake_init)
+    monkeypatch.setattr(dist, "get_backend", lambda: "nccl")
+    seen = []
+    monkeypatch.setattr(dist, "all_reduce", lambda t, op=None: seen.append((t.device, t.dtype, op)))
+    rank, local_rank, world = S.init()
+    assert (rank, local_rank, world) == (3, 3, 8) and calls["set_device"] == 3
+    kw = calls["init"]
+    assert kw["backend"] == "nccl" and kw["rank"] == 3 and kw["world_size"] == 8
+    assert kw["device_id"] == torch.device("cuda", 3)
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["MASTER_PORT"]
+    # the reduces: a float64 scalar on the rank's device (tensor construction itself is mocked away: no GPU here)
+    made = []
+    real_tensor = torch.tensor
+    monkeypatch.setattr(torch, "tensor", lambda data, dtype=None, device=None: (made.append(str(device)), real_tensor(data, dtype=dtype))[1])
+    dev = torch.device("cuda", 3)
+    assert S.max_over_ranks(1.5, dev) == 1.5 and S.sum_over_ranks(2.5, dev) == 2.5
+    assert made == ["cuda:3", "cuda:3"] and [op for _, _, op in seen] == [dist.ReduceOp.MAX, dist.ReduceOp.SUM]
+    monkeypatch.setattr(dist, "get_backend", lambda: "gloo")
+    made.clear()
+    S.max_over_ranks(1.0, dev)
+    assert made == ["cpu"]

@@ -118,7 +118,7 @@ def test_schedule_table_lookup_and_override():
     pick, force = raw.fa_debug_pick, raw.fa_debug_force_impl
     pick.argtypes = [ctypes.c_int] * 8
     force.argtypes = [ctypes.c_int] * 3
-    allowed = {0: {64: {1, 2, 3, 4}, 128: {1, 4}}, 1: {64: {1, 2, 3, 4}, 128: {1}}, 2: {64: {1, 2, 3}, 128: {1, 2}}}
+    allowed = {0: {64: {1, 2, 3, 4}, 128: {1, 4}}, 1: {64: {1, 2, 3, 4}, 128: {1}}, 2: {64: {1, 2, 3, 4}, 128: {1, 2}}}
     for kernel in range(3):
         for D in (64, 128):
             for dtype in (0, 1):
@@ -138,6 +138,10 @@ def test_schedule_table_lookup_and_override():
         assert pick(1, 64, 1, 1, 4, 32, 4096, 4096) == 4 and pick(1, 64, 0, 0, 4, 32, 300, 1024) == 4
         assert pick(1, 64, 1, 0, 4, 32, 512, 500) == 3 and pick(1, 64, 1, 1, 4, 32, 512, 384) == 3   # ragged keys / uncovered tile
         assert pick(1, 64, 1, 1, 1, 2, 200, 512) == 4 and pick(1, 128, 1, 1, 4, 32, 4096, 4096) == 1
+        force(0, 0, 4)   # round 4: the dK/dV kernel on the pinned accumulator file; whole tiles, causal: bf16 with S_q >= S_k
+        assert pick(2, 64, 1, 1, 4, 32, 4096, 4096) == 4 and pick(2, 64, 0, 0, 4, 32, 1024, 512) == 4
+        assert pick(2, 64, 0, 1, 4, 32, 4096, 4096) == 3 and pick(2, 64, 1, 1, 4, 32, 512, 1024) == 3   # fp16 causal / S_q < S_k
+        assert pick(2, 64, 1, 0, 4, 32, 500, 512) == 3 and pick(2, 128, 1, 1, 4, 32, 4096, 4096) == 2
     finally:
         force(0, 0, 0)
     hdr = open(os.path.join(PKG, "csrc", "fa_table.h")).read()

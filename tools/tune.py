@@ -24,7 +24,7 @@ TABLE_H = os.path.join(PKG, "csrc", "fa_table.h")
 BH_BUCKETS = [8, 32, 128, 512]                                  # B*H, nearest in log2
 S_BUCKETS = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]      # max(S_q, S_k), nearest in log2
 KERNELS = ["fwd", "dq", "dkv"]
-CANDIDATES = {"fwd": {64: [1, 2, 3, 4], 128: [1, 4]}, "dq": {64: [1, 2, 3], 128: [1]}, "dkv": {64: [1, 2, 3], 128: [1, 2]}}
+CANDIDATES = {"fwd": {64: [1, 2, 3, 4], 128: [1, 4]}, "dq": {64: [1, 2, 3, 4], 128: [1]}, "dkv": {64: [1, 2, 3, 4], 128: [1, 2]}}
 DTYPES = ["fp16", "bf16"]
 
 
