@@ -97,7 +97,8 @@ constexpr int dq4_cvt_tau(int j) { return j == 0 ? 13 : 14 + (j - 1) / 2; }
 #ifndef FA_DQ4_SPREAD_SLOT
 #define FA_DQ4_SPREAD_SLOT 2
 #endif
-constexpr bool kDq4Spread = FA_DQ4_DMA_SPREAD != 0;
+constexpr bool kDq4Spread = FA_DQ4_DMA_SPREAD != 0;   // (2: the four pairs in the MIDDLE of a tile step, iterations 2 and 4)
+constexpr bool kDq4Mid = FA_DQ4_DMA_SPREAD == 2;
 constexpr int kDq4SpreadSlot = FA_DQ4_SPREAD_SLOT;
 
 template <typename T, bool CAUSAL>
@@ -462,6 +463,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
 
     FA4Q_STAMP(0);
     // ---- the unmasked tiles: eight block iterations per tile, ring slots rotate ----
+#ifdef FA_DQ4_UNROLL2   // A/B hook
+#pragma unroll 2
+#endif
     for (int t = 0; t < nfull; ++t) {
       int kA[C::KS], kN[C::KS], tA[2][C::DB];
       row_bases(kA, b0 * C::TILE_BYTES);
@@ -469,7 +473,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       tr_bases(tA, b0 * C::TILE_BYTES);
       // tile t + 2's V pairs ride in the first iteration (its K pairs went out in the previous tile's last one)
       auto hook_first = [&](int s, int phase) __attribute__((always_inline)) {
-        if constexpr (kDq4Spread) {
+        if constexpr (kDq4Mid) {
+        } else if constexpr (kDq4Spread) {
           if (phase == 1 && s == kDq4SpreadSlot) dma_piece1(t + 2, b2, 0);
         } else {
           if (phase == 1 && s == 1) dma_group(t + 2, b2, 2);
@@ -480,7 +485,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       auto hook_mid = [&](auto i_tag) __attribute__((always_inline)) {
         return [&, i_tag](int s, int phase) __attribute__((always_inline)) {
           constexpr int I = decltype(i_tag)::value;
-          if constexpr (kDq4Spread) {
+          if constexpr (kDq4Mid) {
+            if (I == 2 && phase == 1 && s == 1) dma_group(t + 2, b2, 0);
+            if (I == 2 && phase == 1 && s == 7) dma_group(t + 2, b2, 1);
+            if (I == 4 && phase == 1 && s == 1) dma_group(t + 2, b2, 2);
+            if (I == 4 && phase == 1 && s == 7) dma_group(t + 2, b2, 3);
+          } else if constexpr (kDq4Spread) {
             if (phase == 1 && s == kDq4SpreadSlot) dma_piece1(t + 2, b2, I);
           }
         };
@@ -497,7 +507,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
           asm volatile("" ::: "memory");
           FA4Q_ISTAMP(16);
         }
-        if constexpr (kDq4Spread) {
+        if constexpr (kDq4Mid) {
+        } else if constexpr (kDq4Spread) {
           if (phase == 1 && s == 1) dma_piece1(t + 2, b2, 7);
         } else {
           if (phase == 1 && s == 5) dma_group(t + 3, b0, 0);

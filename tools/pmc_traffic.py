@@ -22,7 +22,8 @@ for f in glob.glob(src + "/p*/**/*counter_collection.csv", recursive=True):
             vals[row["Kernel_Name"].split("fa::")[1].split("<")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 names = {"fa_fwd2_kernel": "fa_fwd", "fa_bwd_dq2_kernel": "fa_bwd_dq", "fa_bwd_dkv2_kernel": "fa_bwd_dkv",
          "fa_fwd3_kernel": "fa_fwd", "fa_bwd_dq3_kernel": "fa_bwd_dq", "fa_fwd4_kernel": "fa_fwd", "fa_bwd_dkv3_kernel": "fa_bwd_dkv",
-         "fa_fwd_kernel": "fa_fwd", "fa_bwd_dq_kernel": "fa_bwd_dq", "fa_bwd_dkv_kernel": "fa_bwd_dkv"}
+         "fa_fwd_kernel": "fa_fwd", "fa_bwd_dq_kernel": "fa_bwd_dq", "fa_bwd_dkv_kernel": "fa_bwd_dkv",
+         "fa_bwd_dq4_kernel": "fa_bwd_dq", "fa_bwd_dkv4_kernel": "fa_bwd_dkv"}
 out = {"source_hash": _bench.kernel_source_hash(), "shape": shape}
 for k, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
