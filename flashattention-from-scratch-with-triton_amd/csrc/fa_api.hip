@@ -98,6 +98,44 @@ int make_dropout(const char* fn, float p_drop, unsigned long long seed, unsigned
 
 }  // namespace
 
+// (fa_debug_poison below)  One wave per SIMD, every register of the wave written, the workgroup's LDS filled.
+__global__ __launch_bounds__(256, 1) void fa_poison_kernel() {
+  extern __shared__ __attribute__((aligned(16))) char poison_smem[];
+  const unsigned nan2 = 0x7FC07FC0u;
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) ((unsigned*)poison_smem)[i] = nan2;
+#define FA_P4(n) "v_mov_b32 v" #n ", %0\n\tv_accvgpr_write_b32 a" #n ", %0\n\t"
+#define FA_P16(a, b, c, d) FA_P4(a) FA_P4(b) FA_P4(c) FA_P4(d)
+  // v8 .. v255 and a0 .. a255 (v0 .. v7 stay with the compiler: the loop above and the kernel's few addresses)
+  asm volatile(
+      FA_P16(8, 9, 10, 11) FA_P16(12, 13, 14, 15) FA_P16(16, 17, 18, 19) FA_P16(20, 21, 22, 23) FA_P16(24, 25, 26, 27) FA_P16(28, 29, 30, 31)
+      FA_P16(32, 33, 34, 35) FA_P16(36, 37, 38, 39) FA_P16(40, 41, 42, 43) FA_P16(44, 45, 46, 47) FA_P16(48, 49, 50, 51) FA_P16(52, 53, 54, 55)
+      FA_P16(56, 57, 58, 59) FA_P16(60, 61, 62, 63) FA_P16(64, 65, 66, 67) FA_P16(68, 69, 70, 71) FA_P16(72, 73, 74, 75) FA_P16(76, 77, 78, 79)
+      FA_P16(80, 81, 82, 83) FA_P16(84, 85, 86, 87) FA_P16(88, 89, 90, 91) FA_P16(92, 93, 94, 95) FA_P16(96, 97, 98, 99) FA_P16(100, 101, 102, 103)
+      FA_P16(104, 105, 106, 107) FA_P16(108, 109, 110, 111) FA_P16(112, 113, 114, 115) FA_P16(116, 117, 118, 119) FA_P16(120, 121, 122, 123)
+      FA_P16(124, 125, 126, 127) FA_P16(128, 129, 130, 131) FA_P16(132, 133, 134, 135) FA_P16(136, 137, 138, 139) FA_P16(140, 141, 142, 143)
+      FA_P16(144, 145, 146, 147) FA_P16(148, 149, 150, 151) FA_P16(152, 153, 154, 155) FA_P16(156, 157, 158, 159) FA_P16(160, 161, 162, 163)
+      FA_P16(164, 165, 166, 167) FA_P16(168, 169, 170, 171) FA_P16(172, 173, 174, 175) FA_P16(176, 177, 178, 179) FA_P16(180, 181, 182, 183)
+      FA_P16(184, 185, 186, 187) FA_P16(188, 189, 190, 191) FA_P16(192, 193, 194, 195) FA_P16(196, 197, 198, 199) FA_P16(200, 201, 202, 203)
+      FA_P16(204, 205, 206, 207) FA_P16(208, 209, 210, 211) FA_P16(212, 213, 214, 215) FA_P16(216, 217, 218, 219) FA_P16(220, 221, 222, 223)
+      FA_P16(224, 225, 226, 227) FA_P16(228, 229, 230, 231) FA_P16(232, 233, 234, 235) FA_P16(236, 237, 238, 239) FA_P16(240, 241, 242, 243)
+      FA_P16(244, 245, 246, 247) FA_P16(248, 249, 250, 251) FA_P16(252, 253, 254, 255)
+      "v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %0\n\tv_accvgpr_write_b32 a2, %0\n\tv_accvgpr_write_b32 a3, %0\n\t"
+      "v_accvgpr_write_b32 a4, %0\n\tv_accvgpr_write_b32 a5, %0\n\tv_accvgpr_write_b32 a6, %0\n\tv_accvgpr_write_b32 a7, %0"
+      :: "v"(nan2)
+      : "memory"
+#define FA_C(n) , "v" #n, "a" #n
+#define FA_C8(n) FA_C(n##0) FA_C(n##1) FA_C(n##2) FA_C(n##3) FA_C(n##4) FA_C(n##5) FA_C(n##6) FA_C(n##7) FA_C(n##8) FA_C(n##9)
+        , "v8", "v9", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9"
+        FA_C8(1) FA_C8(2) FA_C8(3) FA_C8(4) FA_C8(5) FA_C8(6) FA_C8(7) FA_C8(8) FA_C8(9) FA_C8(10) FA_C8(11) FA_C8(12) FA_C8(13) FA_C8(14)
+        FA_C8(15) FA_C8(16) FA_C8(17) FA_C8(18) FA_C8(19) FA_C8(20) FA_C8(21) FA_C8(22) FA_C8(23) FA_C8(24)
+        FA_C(250) FA_C(251) FA_C(252) FA_C(253) FA_C(254) FA_C(255));
+#undef FA_C8
+#undef FA_C
+#undef FA_P16
+#undef FA_P4
+  __syncthreads();
+}
+
 extern "C" {
 
 int fa_abi_version(void) { return MI355FA_ABI_VERSION; }
@@ -120,6 +158,18 @@ int fa_debug_pick(int kernel, int D, int dtype, int causal, int B, int H, int S_
 // Not part of the public header: diagnostic hook used by tools/stamps*.py with -DFA_STAMPS builds; in the product library the
 // family-4 forward counts, in the buffer's first word, the passes that took their exact second attempt (tests).
 void fa_debug_set_buffer(void* p) { g_dbg = p; }
+
+// Not part of the public header: fill every CU's LDS (160 KiB) and every vector / accumulator register a workgroup of the
+// family-4 kernels can own with NaN patterns (0x7FC07FC0: a NaN as fp32, as two bf16 and as two fp16).  Tests and
+// tools/race_check.py launch it between kernels: a kernel that reads LDS or a register it has not written -- a missing
+// wait on an LDS-DMA piece, an accumulator that is not zeroed -- otherwise finds what the PREVIOUS launch left there,
+// which in a test that repeats one launch is exactly the right data.
+int fa_debug_poison(void* stream) {
+  static std::atomic<unsigned long long> opted_in{0};
+  if (hipError_t e = fa::opt_in_lds((const void*)fa_poison_kernel, 160 * 1024, opted_in)) return (int)e;
+  hipLaunchKernelGGL(fa_poison_kernel, dim3(2048), dim3(256), 160 * 1024, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
 
 const char* fa_last_error(void) { return g_err; }
 

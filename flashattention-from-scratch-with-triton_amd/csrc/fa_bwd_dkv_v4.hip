@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
   };
   auto decode = [&](int item) __attribute__((always_inline)) -> Work {
     const int w = xcd_remap(item, n_items);
-    const int bh = w / per_bh, idx = w - bh * per_bh, b = bh / p.H;
+    const int bh = p.div_per_bh.div(w), idx = w - bh * per_bh, b = p.div_h.div(bh);   // (fa_kernels.h FastDiv)
     return Work{b, bh - b * p.H, idx, (paired && idx != nk - 1 - idx) ? 2 : 1};
   };
   auto ktile_of = [&](const Work& wk, int pass) __attribute__((always_inline)) -> int {   // low key tiles are the heavy ones
@@ -152,9 +152,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
 
   int item = blockIdx.x;
   Work wk = decode(item);
+  Work nwk_item = decode(min(item + (int)gridDim.x, n_items - 1));   // the workgroup's next item, decoded once per item
   int b0 = 0, b1 = 1, b2 = 2;   // ring slots of stream positions i, i + 1, i + 2; they keep rotating from pass to pass
   bool staged = false;          // this pass's rows are on their way (issued from inside the previous pass)
-  for (; item < n_items; item += gridDim.x, wk = decode(min(item, n_items - 1))) {
+  for (; item < n_items; item += gridDim.x, wk = nwk_item, nwk_item = decode(min(item + (int)gridDim.x, n_items - 1))) {
   const int b_ = wk.b, h_ = wk.h, npass = wk.npass;
   const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc((const char*)p.dout + b_ * p.ldo.sb + h_ * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
@@ -236,10 +237,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       pin_write<C::F_K + 4 * g + ks>(__builtin_bit_cast(u32x4, kk));
       pin_write<C::F_V + 4 * g + ks>(lds_read16(smem + (g ? C::DO_BASE : 0) + b2 * C::TILE_BYTES + wave * C::KG_BYTES + row_off[ks]));
     });
-    // the V rows are consumed (every read above has fed a register write): this wave's part of slot b2 takes position 2
     __builtin_amdgcn_sched_barrier(0);
-    dma_group(2, b2, 0);
-    dma_group(2, b2, 1);
     static_for<8>([](auto i_) __attribute__((always_inline)) { acc_zero16<16 * decltype(i_)::value>(); });
 
     // ---- loop-invariant per-lane LDS offsets ----
@@ -439,10 +437,17 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       for (int n = 0; n < 8; ++n) TF[n] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
     };
 
-    // ---- stream position 0 is current: everything but the four pieces of position 2 requested last has landed ----
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // ---- stream position 0 is current: positions 0 and 1 and the first row constant have landed ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     rc_publish(RC0{}, b0);
     rc_request(RC0{}, 1);   // the steady state keeps ONE row-constant request in flight, in a[192]
+    // The V rows are consumed (every read above has fed a register write): this wave's part of slot b2 takes position 2 --
+    // requested AFTER the row constant of position 1, the order of the steady state (a commit requests the next row
+    // constant, then the Q pairs, then the dO pairs): the first commit's vmcnt(8) covers the eight newest requests, and with
+    // the Q pairs of position 2 in front of it the row constant was one of them -- published from a[192] before it had
+    // landed once in ~30 launches under load (tools/race_stress.py; round 4), a whole dK / dV tile wrong.
+    dma_group(2, b2, 0);
+    dma_group(2, b2, 1);
     asm volatile("s_nop 4");  // v_accvgpr_write -> MFMA operand wait states (hipcc pads nothing around asm)
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the row constants are written
     __builtin_amdgcn_s_barrier();
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       // (the pair's second pass, or the first pass of the workgroup's next item).  The four piece groups ride in the three
       // block iterations below that every wave executes exactly once; with nothing to follow the descriptors are empty.
       const bool more_pass = pass + 1 < npass, more_item = item + (int)gridDim.x < n_items;
-      const Stage nst = stage_of(more_pass ? wk : decode(min(item + (int)gridDim.x, n_items - 1)), more_pass ? pass + 1 : 0,
+      const Stage nst = stage_of(more_pass ? wk : nwk_item, more_pass ? pass + 1 : 0,
                                  more_pass || more_item);
       auto hook_a = [&](int s, int phase) __attribute__((always_inline)) {
         if (phase == 1 && s == 2) stage_group(nst, b2, 0);
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       if (staged) {   // something follows: its first two tiles and its first row constant are requested NOW -- the ring is free
                       // since the barrier above -- and land while dK / dV are written out
         const bool more_pass = pass + 1 < npass;
-        const Work nw = more_pass ? wk : decode(item + (int)gridDim.x);
+        const Work nw = more_pass ? wk : nwk_item;
         const int t0n = ktile_of(nw, more_pass ? pass + 1 : 0) * C::BK / C::BQ, n_mainn = ntiles - t0n - 2;
         const int tn0 = n_mainn > 0 ? t0n + 2 : t0n, tn1 = n_mainn > 1 ? t0n + 3 : (n_mainn == 1 ? t0n : t0n + 1);
         const __amdgpu_buffer_rsrc_t nrq = make_rsrc((const char*)p.q + nw.b * p.lq.sb + nw.h * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
@@ -670,6 +675,8 @@ static hipError_t launch4(const BwdParams& p, hipStream_t s) {
 hipError_t launch_bwd_dkv_v4(BwdParams p, int dtype, int causal, hipStream_t s) {
   p.n_tiles = (p.Sk + Dkv4Cfg::BK - 1) / Dkv4Cfg::BK;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
+  p.div_per_bh = make_fastdiv(p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles);
+  p.div_h = make_fastdiv(p.H);
   if (dtype == 1) return causal ? launch4<BF16, true>(p, s) : launch4<BF16, false>(p, s);
   // (fp16 causal stays with family 3: the exact-fma path keeps two sets of -LSE*log2e blocks, and with the diagonal phase's
   // chain start on top the kernel spills 500 registers; fa_kernels.h pick_dkv_impl never sends it here)

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
   };
   auto decode = [&](int item) __attribute__((always_inline)) -> Work {
     const int w = xcd_remap(item, n_items);
-    const int bh = w / per_bh, idx = w - bh * per_bh, b = bh / p.H;
+    const int bh = p.div_per_bh.div(w), idx = w - bh * per_bh, b = p.div_h.div(bh);   // (fa_kernels.h FastDiv)
     return Work{b, bh - b * p.H, idx, (paired && idx != nq - 1 - idx) ? 2 : 1};
   };
   auto tile_of = [&](const Work& wk, int pass) __attribute__((always_inline)) -> int {   // heavy tile first
@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
 
   int item = blockIdx.x;
   Work wk = decode(item);
+  Work nwk_item = decode(min(item + (int)gridDim.x, n_items - 1));   // the workgroup's next item, decoded once per item
   int b0 = 0, b1 = 1, b2 = 2;   // ring slots of tiles t, t + 1, t + 2; they keep rotating from pass to pass
   bool staged = false;          // this pass's rows are on their way (issued from inside the previous pass)
-  for (; item < n_items; item += gridDim.x, wk = decode(min(item, n_items - 1))) {
+  for (; item < n_items; item += gridDim.x, wk = nwk_item, nwk_item = decode(min(item + (int)gridDim.x, n_items - 1))) {
   const int b_ = wk.b, h_ = wk.h, npass = wk.npass;
   const __amdgpu_buffer_rsrc_t rdq = make_rsrc((char*)p.dq + b_ * p.ldq.sb + h_ * p.ldq.sh, view_bytes(Sq, dq_rs, C::ROWB));
   const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, view_bytes(Sk, kv_rs, C::ROWB));
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       };
       // (spread placement: piece I of tile t + 2 rides in block iteration I, all of them in front of this step's commit)
       auto hook_mid = [&](auto i_tag) __attribute__((always_inline)) {
-        return [&, i_tag](int s, int phase) __attribute__((always_inline)) {
+        return [&](int s, int phase) __attribute__((always_inline)) {
           constexpr int I = decltype(i_tag)::value;
           if constexpr (kDq4Mid) {
             if (I == 2 && phase == 1 && s == 1) dma_group(t + 2, b2, 0);
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       // pair's second pass, or the first pass of the workgroup's next item).  The six piece groups ride in the three block
       // iterations below that every wave executes exactly once; with nothing to follow the descriptors are empty.
       const bool more_pass = pass + 1 < npass, more_item = item + (int)gridDim.x < n_items;
-      const Stage nst = stage_of(more_pass ? wk : decode(min(item + (int)gridDim.x, n_items - 1)), more_pass ? pass + 1 : 0,
+      const Stage nst = stage_of(more_pass ? wk : nwk_item, more_pass ? pass + 1 : 0,
                                  more_pass || more_item);
       auto hook_a = [&](int s, int phase) __attribute__((always_inline)) {
         if (phase == 1 && s == 2) stage_group(nst, b2, 0);
@@ -683,6 +684,8 @@ static hipError_t launch4(const BwdParams& p, hipStream_t s) {
 hipError_t launch_bwd_dq_v4(BwdParams p, int dtype, int causal, hipStream_t s) {
   p.n_tiles = (p.Sq + Dq4Cfg::BM - 1) / Dq4Cfg::BM;
   p.pair = want_pairs(causal != 0, p.n_tiles, (long)p.B * p.H);
+  p.div_per_bh = make_fastdiv(p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles);
+  p.div_h = make_fastdiv(p.H);
   if (dtype == 1) return causal ? launch4<BF16, true>(p, s) : launch4<BF16, false>(p, s);
   return causal ? launch4<FP16, true>(p, s) : launch4<FP16, false>(p, s);
 }

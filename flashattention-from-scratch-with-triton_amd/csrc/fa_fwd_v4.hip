@@ -49,7 +49,12 @@ struct Fwd4Cfg {
   static constexpr int TILE_BYTES = BN * ROWB;              // 16 KiB for both head dims
   static constexpr int V_BASE = NBUF * TILE_BYTES;          // K[NBUF], then V[NBUF]
   static constexpr int FLAG_OFF = 2 * NBUF * TILE_BYTES;    // one word: some wave's row sums overflowed
-  static constexpr int LDS_BYTES = FLAG_OFF + 16;
+  // behind the flag (D = 64; at D = 128 the ring leaves no room): the NEXT pass's Q rows, 64 per wave (two 32-row blocks
+  // of 4 KiB in the K tiles' swizzled row image), staged by LDS-DMA from inside the previous pass (the kernel says when)
+  static constexpr int RB_BYTES = 32 * ROWB;
+  static constexpr int QS_OFF = FLAG_OFF + 16;
+  static constexpr int QS_BYTES = D == 64 ? 8 * RB_BYTES : 0;
+  static constexpr int LDS_BYTES = QS_OFF + QS_BYTES;
   static constexpr int PIECES = TILE_BYTES / (NW * 1024);   // 1-KiB LDS-DMA pieces per wave per matrix (4)
   static constexpr int RPI = 1024 / ROWB;                   // tile rows per piece
   // A/B hook, OFF: row sums on the MATRIX pipe (l^T += 1^T P^T: one more MFMA per (k-step, row block) with an all-ones A
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
 #ifdef FA_STAMPS
   unsigned long long clk0_, rt0_;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_), "=s"(rt0_)::"memory");
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = clk0_, ntile_ = 0, npass_ = 0;
 #endif
   using C = Fwd4Cfg<D>;
@@ -108,22 +113,41 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  // Work list: one item = one 256-row query tile, or (causal) the tile pair (nq-1-i, i) -> equal work per item.  Causal
+  // launches are PERSISTENT: a workgroup per CU walks items blockIdx.x, blockIdx.x + gridDim.x, ... (a multiple of 8 keeps a
+  // workgroup on one XCD's slice list), because a pass's first K/V tiles and its Q rows are fetched from inside the PREVIOUS
+  // pass (CONT / STAGEQ below) and the first pass of an item has no previous pass unless the workgroup stays.
+  constexpr bool CONT = CAUSAL;                // the K/V ring runs on from pass to pass (and from item to item)
+  constexpr bool STAGEQ = CAUSAL && D == 64;   // the next pass's Q rows come through LDS (Fwd4Cfg::QS_OFF)
   const bool paired = CAUSAL && p.pair;
-  const int per_bh = paired ? (p.nq_tiles + 1) / 2 : p.nq_tiles;
-  const int bh = w / per_bh;
-  const int idx = w - bh * per_bh;
-  const int npass = (paired && idx != p.nq_tiles - 1 - idx) ? 2 : 1;
-  const int b_ = bh / p.H, h_ = bh - b_ * p.H;
+  const int nq = p.nq_tiles;
+  const int per_bh = paired ? (nq + 1) / 2 : nq;
+  const int n_items = per_bh * p.B * p.H;
   const int Sq = p.Sq, Sk = p.Sk;
+  struct Work {
+    int b, h, idx, npass;
+  };
+  auto decode = [&](int item) __attribute__((always_inline)) -> Work {
+    const int w = xcd_remap(item, n_items);
+    const int bh = p.div_per_bh.div(w), idx = w - bh * per_bh, b = p.div_h.div(bh);   // (fa_kernels.h FastDiv)
+    return Work{b, bh - b * p.H, idx, (paired && idx != nq - 1 - idx) ? 2 : 1};
+  };
+  auto tile_of = [&](const Work& wk, int pass) __attribute__((always_inline)) -> int {   // heavy tile first
+    return paired ? (pass == 0 ? nq - 1 - wk.idx : wk.idx) : (CAUSAL ? nq - 1 - wk.idx : wk.idx);
+  };
 
   // Q, K, V, O may be strided views with a contiguous head dim (fa_fwd.hip); no variable-length launches here
   const int q_rs = p.lq.rs, kv_rs = p.lk.rs, o_rs = p.lo.rs;
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc((const char*)p.q + b_ * p.lq.sb + h_ * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc((const char*)p.k + b_ * p.lk.sb + h_ * p.lk.sh, view_bytes(Sk, kv_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc((const char*)p.v + b_ * p.lv.sb + h_ * p.lv.sh, view_bytes(Sk, kv_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh, view_bytes(Sq, o_rs, C::ROWB));
-  const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
+  // (a descriptor that is not `valid` -- nothing follows the last pass -- is empty: its pieces fetch nothing)
+  auto rsrc_q = [&](const Work& wk, bool valid) __attribute__((always_inline)) {
+    return make_rsrc((const char*)p.q + wk.b * p.lq.sb + wk.h * p.lq.sh, valid ? view_bytes(Sq, q_rs, C::ROWB) : 0u);
+  };
+  auto rsrc_k = [&](const Work& wk, bool valid) __attribute__((always_inline)) {
+    return make_rsrc((const char*)p.k + wk.b * p.lk.sb + wk.h * p.lk.sh, valid ? view_bytes(Sk, kv_rs, C::ROWB) : 0u);
+  };
+  auto rsrc_v = [&](const Work& wk, bool valid) __attribute__((always_inline)) {
+    return make_rsrc((const char*)p.v + wk.b * p.lv.sb + wk.h * p.lv.sh, valid ? view_bytes(Sk, kv_rs, C::ROWB) : 0u);
+  };
 
   // ---- loop-invariant per-lane addresses ----
   int dma_src[C::PIECES];   // per-lane global source offset of this wave's pieces (K and V share their row stride)
@@ -149,11 +173,25 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
   }
 
   if (tid == 0) *(FA_LDS int*)(smem + C::FLAG_OFF) = 0;   // "some wave's row sums overflowed" (ordered by the first barrier below)
-  bool primed = false;   // the first NBUF - 1 tiles of the ring are on their way (issued before the previous pass's epilogue)
+  bool primed = false;   // CONT: this pass's first NBUF - 1 tiles (and, STAGEQ, its Q rows) were requested from inside the previous pass
+  int r0 = 0;            // ring slot of the pass's tile 0: tile t sits in slot (r0 + t) % NBUF
 
-  for (int pass = 0; pass < npass; ++pass) {
-    const int qt = paired ? (pass == 0 ? p.nq_tiles - 1 - idx : idx) : (CAUSAL ? p.nq_tiles - 1 - idx : idx);  // heavy first
-    const int q0_wg = qt * C::BM;
+  int item = blockIdx.x, pass = 0;
+  Work wk = decode(item);
+  Work nwk_item = decode(min(item + (int)gridDim.x, n_items - 1));   // the workgroup's next item, decoded once
+  for (;;) {
+    const int b_ = wk.b, h_ = wk.h;
+    const __amdgpu_buffer_rsrc_t rk = rsrc_k(wk, true), rv = rsrc_v(wk, true);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)p.o + b_ * p.lo.sb + h_ * p.lo.sh, view_bytes(Sq, o_rs, C::ROWB));
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(p.lse + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
+    // what follows this pass: the pair's second pass, or the first pass of the workgroup's next item
+    const bool more_pass = pass + 1 < wk.npass, more_item = item + (int)gridDim.x < n_items;
+    const bool has_next = CONT && (more_pass || more_item);
+    const Work nwk = more_pass ? wk : nwk_item;
+    const int nq0_wg = tile_of(nwk, more_pass ? pass + 1 : 0) * C::BM;
+
+    FA4_STAMP(8);   // seg[8]: loop bookkeeping (the next item decoded, descriptors)
+    const int q0_wg = tile_of(wk, pass) * C::BM;
     // this wave's two 32-row blocks: rows qrow(rb) + r with qrow(rb) = q0_wg + 128 rb + 32 wave -- one block in each half
     // of the 256-row tile, so that under the causal mask the SECOND half of the key tiles level with the query tile is
     // invisible to row block 0 of EVERY wave (skipped outright) and the first half is unmasked for every row block 1
@@ -166,34 +204,75 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
     const int nplain = CAUSAL ? min(Sk / C::BN, q0_wg / C::BN) : Sk / C::BN;
 
     // ---- LDS-DMA of one K/V tile: 2 x PIECES pieces per wave, issued in pairs (one M0 write each) ----
-    auto dma_pair = [&](int t, int slot, int j) __attribute__((always_inline)) {   // j: 0 .. PIECES-1; pairs 0 .. PIECES/2-1 K, then V
-      constexpr int HALF = C::PIECES / 2;
+    auto dma_pair_of = [&](const __amdgpu_buffer_rsrc_t& rkx, const __amdgpu_buffer_rsrc_t& rvx, int t, int slot, int j) __attribute__((always_inline)) {
+      constexpr int HALF = C::PIECES / 2;   // j: 0 .. PIECES-1; pairs 0 .. PIECES/2-1 K, then V
       const int i = 2 * (j % HALF);
       const int dst = slot * C::TILE_BYTES + ((C::BN / C::NW) * wave + C::RPI * i) * C::ROWB;
-      if (j < HALF) dma_pieces<2>(rk, lds_addr_of(smem + dst), dma_src + i, t * C::BN * kv_rs);
-      else dma_pieces<2>(rv, lds_addr_of(smem + C::V_BASE + dst), dma_src + i, t * C::BN * kv_rs);
+      if (j < HALF) dma_pieces<2>(rkx, lds_addr_of(smem + dst), dma_src + i, t * C::BN * kv_rs);
+      else dma_pieces<2>(rvx, lds_addr_of(smem + C::V_BASE + dst), dma_src + i, t * C::BN * kv_rs);
     };
-    auto fetch_tile = [&](int t) __attribute__((always_inline)) {
+    auto dma_pair = [&](int t, int slot, int j) __attribute__((always_inline)) { dma_pair_of(rk, rv, t, slot, j); };
+    auto fetch_tile = [&](int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < C::PIECES; ++j) dma_pair(t, t % C::NBUF, j);
+      for (int j = 0; j < C::PIECES; ++j) dma_pair(t, slot, j);
+    };
+    // Q rows of row block rb of the query tile at q0 -> this wave's part of the staging area, as two pairs of 1-KiB pieces
+    // (8 rows each) in the K tiles' swizzled row image: the fragments are then ds_read_b128 row reads like K's.  Fetched as
+    // fragments (8 loads per lane, each touching 32 cache lines) the same rows cost the CU's address unit ~63 cycles per
+    // load and the wave the whole memory latency at the top of a pass (fa_bwd_dq_v4.hip; profiles/r04_ab_lines.txt).
+    auto stage_q_pair = [&](const __amdgpu_buffer_rsrc_t& rqx, int q0, int rb, int hf) __attribute__((always_inline)) {
+      if constexpr (STAGEQ) {
+        const int prow = lane >> 3;
+        int voff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = 8 * (2 * hf + i) + prow;   // row of the 32-row block
+          voff[i] = (q0 + 128 * rb + 32 * wave + row) * q_rs + swz_chunk<D>(row, lane & 7) * 16 - 1024 * i;
+        }
+        dma_pieces<2>(rqx, lds_addr_of(smem + C::QS_OFF + (2 * wave + rb) * C::RB_BYTES + 2048 * hf), voff, 0);
+      }
     };
     // The K/V tiles do not depend on the query tile: the ring is primed BEFORE the Q fragments are fetched (one memory
-    // latency per pass instead of two), for a second pass already before the first pass's epilogue.
+    // latency per pass instead of two).  Only the first pass of a causal workgroup (and every non-causal pass) comes here
+    // unprimed: later passes found their first tiles and Q rows requested by the masked tiles of the pass before.
+    const bool was_primed = primed;
     if (!primed) {
+      r0 = 0;
+      if constexpr (STAGEQ) {
+        const __amdgpu_buffer_rsrc_t rq = rsrc_q(wk, true);
 #pragma unroll
-      for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
-      primed = true;
+        for (int g = 0; g < 4; ++g) stage_q_pair(rq, q0_wg, g >> 1, g & 1);
+      }
+#pragma unroll
+      for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t, t);
     }
+    FA4_STAMP(9);   // seg[9]: an unprimed pass's requests
     // ---- resident operands: Q^T fragments of both row blocks (B operand), scaled once (bf16) ----
     u32x4 qf[2][C::KS];
+    if constexpr (STAGEQ) {
+      // this wave's own pieces, nobody else's: no barrier.  Primed passes waited at the previous end-of-pass check.
+      if (!was_primed) __builtin_amdgcn_s_waitcnt(0x0F70 | (((C::NBUF - 1) * 2 * C::PIECES) & 15) | ((((C::NBUF - 1) * 2 * C::PIECES) >> 4) << 14));
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        vec8 q = as_vec8<T>(buf_load16(rq, (qrow(rb) + r) * q_rs + (2 * ks + h) * 16));
-        if constexpr (FOLD) q = scale_frag<T>(q, c2);
-        qf[rb][ks] = __builtin_bit_cast(u32x4, q);
-      }
+        for (int ks = 0; ks < C::KS; ++ks) {
+          vec8 q = as_vec8<T>(lds_read16(smem + C::QS_OFF + (2 * wave + rb) * C::RB_BYTES + k_off[ks]));
+          if constexpr (FOLD) q = scale_frag<T>(q, c2);
+          qf[rb][ks] = __builtin_bit_cast(u32x4, q);
+        }
+    } else {
+      const __amdgpu_buffer_rsrc_t rq = rsrc_q(wk, true);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          vec8 q = as_vec8<T>(buf_load16(rq, (qrow(rb) + r) * q_rs + (2 * ks + h) * 16));
+          if constexpr (FOLD) q = scale_frag<T>(q, c2);
+          qf[rb][ks] = __builtin_bit_cast(u32x4, q);
+        }
+    }
+    FA4_STAMP(10);   // seg[10]: Q fragments
     // per-lane mask base: score register i of lane (r, h) in a block starting at key kb0 is key kb0 + c_i + 4h, row
     // qrow(rb) + r; it is dead iff the key exceeds the row (causal) or the last key:  c_i > thr = base[rb] - kb0
     int mask_base[2];
@@ -340,11 +419,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       }
     };
     // the last key block's remaining softmax and its P V once nothing follows it
-    auto drain = [&](auto set_tag, auto pst_tag, int t_last) __attribute__((always_inline)) {
+    auto drain = [&](auto set_tag, auto pst_tag, int rt_last) __attribute__((always_inline)) {   // rt_last: the last tile's ring slot
       constexpr int PSET = decltype(set_tag)::value ^ 1, PST = decltype(pst_tag)::value;
       constexpr bool PREV0 = PST != 2;
       if constexpr (!C::LSUM) {   // the last V^T fragment of the last key block (slot 0 of the following iteration in the steady state)
-        const int base = C::V_BASE + (t_last % C::NBUF) * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB + 16 * C::ROWB;
+        const int base = C::V_BASE + rt_last * C::TILE_BYTES + (C::NKB - 1) * 32 * C::ROWB + 16 * C::ROWB;
         VF[2 * C::DB - 1] = lds_read_tr_frag<T>(smem + v_off[0][C::DB - 1] + base, smem + v_off[1][C::DB - 1] + base);
       }
 #pragma unroll
@@ -361,9 +440,16 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       }
     };
 
-    // one tile: NKB block iterations; the commit + the DMA of tile t + NBUF - 1 ride in the last one
-    auto tile_step = [&](int t, int rt, auto mode_tag, auto pst_tag) __attribute__((always_inline)) {   // rt = t % NBUF (kept by the caller)
-      constexpr int MODE = decltype(mode_tag)::value;
+    // one tile: NKB block iterations; the commit + the DMA of tile t + NBUF - 1 ride in the last one.  NX != 0 (CONT: the
+    // pass's last NBUF - 1 tiles): that tile lies past the end of the pass -- it is tile t + NBUF - 1 - ntiles of the NEXT
+    // pass, which thereby finds its ring primed and simply runs on (r0); NX == 2 also carries the next pass's Q rows
+    // (STAGEQ: four pairs of pieces, two in each of the first two block iterations).
+    auto tile_step = [&](int t, int rt, auto mode_tag, auto pst_tag, auto nx_tag) __attribute__((always_inline)) {   // rt: the tile's ring slot (kept by the caller)
+      constexpr int MODE = decltype(mode_tag)::value, NX = decltype(nx_tag)::value;
+      // (the next pass's descriptors are put together where they are used: seven descriptors live across the plain-tile
+      //  loop cost scalar registers the loop does not have)
+      const __amdgpu_buffer_rsrc_t nrk = rsrc_k(nwk, has_next && NX != 0), nrv = rsrc_v(nwk, has_next && NX != 0);
+      const __amdgpu_buffer_rsrc_t nrq = rsrc_q(nwk, has_next && NX == 2);
       using OwnSt = std::integral_constant<int, MODE == 0 ? 0 : (MODE == 3 ? 2 : 1)>;   // what a block of this tile is to its successor
       const int rn = rt + 1 == C::NBUF ? 0 : rt + 1, rp = rt == 0 ? C::NBUF - 1 : rt - 1;
       const int lds0 = (int)lds_addr_of(smem);   // inside the opaque bases: otherwise every address costs a second add
@@ -388,7 +474,14 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
           if (s == 1) commit();   // before the first read of tile t + 1 (slot 2), after every read of tile t - 1
 #pragma unroll
           for (int j = 0; j < C::PIECES; ++j)
-            if (s == C::NSS + 1 + 2 * j) dma_pair(t + C::NBUF - 1, rp, j);   // into the buffer tile t - 1 has just left
+            if (s == C::NSS + 1 + 2 * j) {   // into the buffer tile t - 1 has just left
+              if constexpr (NX != 0) dma_pair_of(nrk, nrv, t + C::NBUF - 1 - ntiles, rp, j);
+              else dma_pair(t + C::NBUF - 1, rp, j);
+            }
+        }
+        if constexpr (NX == 2 && STAGEQ) {
+          if (J < 2 && s == C::NSS + 1) stage_q_pair(nrq, nq0_wg, J, 0);
+          if (J < 2 && s == C::NSS + 5) stage_q_pair(nrq, nq0_wg, J, 1);
         }
       };
       auto go = [&](auto j_tag) __attribute__((always_inline)) {
@@ -421,7 +514,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
 #pragma unroll
         for (int ks = 1; ks < C::KS; ++ks) T::mfma_v_acc(s, lds_read16(kblk + k_off[ks]), qf[rb][ks]);
         settle_mfma(s);   // asm MFMA result -> VALU reader (hipcc pads nothing around asm)
-        const int th = mask_base[rb] - kb0;
+        // (opaque: the first attempt's thresholds do not change inside the attempt loop, and hipcc hoists the 32 compares
+        //  out of it -- into 32 scalar register PAIRS it does not have: ~130 lane spills and refills per pass)
+        const int th = opaque(mask_base[rb] - kb0);
         float mm = mx[rb];
 #pragma unroll
         for (int i = 0; i < 16; ++i) mm = __builtin_fmaxf(mm, (i & 3) + 8 * (i >> 2) > th ? -INFINITY : s[i]);
@@ -444,16 +539,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
 
     for (int attempt = 0; attempt < 2; ++attempt) {
       // ---- prologue: the first NBUF - 1 tiles on their way, tile 0 landed ----
-      if (!primed) {
+      if (attempt == 1) {   // (the ring restarts at slot 0; the barrier of the redo branch below came first)
+        r0 = 0;
 #pragma unroll
-        for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+        for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t, t);
       }
-      primed = false;
-      asm volatile("" ::: "memory");
-      // tile 0 = the oldest 2 * PIECES pieces: leave the later tiles' pieces in flight
-      __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      if (!was_primed || attempt == 1) {
+        asm volatile("" ::: "memory");
+        // tile 0 = the oldest 2 * PIECES pieces: leave the later tiles' pieces in flight
+        __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }   // (a primed pass: the previous end-of-pass check waited for tile 0 and held the barrier)
 
       FA4_STAMP(0);   // seg[0]: pass prologue -- Q fragments, ring primed, tile 0 landed (first barrier)
       float mx[2] = {-INFINITY, -INFINITY};
@@ -463,14 +560,14 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         //  longer cancels against l, O picks up a second rounding (<= 2^-9), and a row with ONE visible key gets a dQ of
         //  5e-2 instead of exactly 0 (tests/test_gpu_fuzz.py).  The scout keeps that property for every row whose maximum
         //  lies in its first 32 keys, and costs 8 MFMAs per pass.)
-        scout_block(smem, 0, mx);                 // keys 0..31: key 0 is visible to every row (top-left aligned mask)
+        scout_block(smem + r0 * C::TILE_BYTES, 0, mx);   // keys 0..31: key 0 is visible to every row (top-left aligned mask)
         set_m(mx);
       } else {
         // exact row maxima: a max-only sweep over every tile (cold path: reached only after an overflow)
         for (int t = 0; t < ntiles; ++t) {
           if (t > 0) {
             __syncthreads();
-            fetch_tile(t);
+            fetch_tile(t, t % C::NBUF);
             __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
             __syncthreads();
           }
@@ -482,7 +579,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         __builtin_amdgcn_s_waitcnt(0x0070);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
+        for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t, t);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
         __builtin_amdgcn_s_barrier();
@@ -514,18 +611,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
         thr[0][rb] = thr[1][rb] = 1 << 20;   // neutral: nothing is masked (plain blocks never touch their threshold)
       }
 #pragma unroll
-      for (int ks = 0; ks < KR; ++ks) KF[ks] = lds_read16(smem + k_off[ks]);
+      for (int ks = 0; ks < KR; ++ks) KF[ks] = lds_read16(smem + r0 * C::TILE_BYTES + k_off[ks]);
 #pragma unroll
       for (int pp = 0; pp < 2 * C::DB; ++pp) VF[pp] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
       __builtin_amdgcn_sched_barrier(0);
 
       FA4_STAMP(2);   // seg[2]: pipeline fill
-      int t = 0, rt = 0;
+      int t = 0, rt = r0;
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
-      for (; t < nplain; ++t, rt = rt + 1 == C::NBUF ? 0 : rt + 1) tile_step(t, rt, I0{}, I0{});
+      for (; t < nplain; ++t, rt = rt + 1 == C::NBUF ? 0 : rt + 1) tile_step(t, rt, I0{}, I0{}, I0{});
 #ifdef FA_STAMPS
       FA4_STAMP(3);   // seg[3]: the plain tiles
       ntile_ += nplain;
@@ -544,24 +641,29 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       if constexpr (CAUSAL) {
         // the launcher sends a causal shape here only if every query tile has all 256 keys level with it (S_k a multiple
         // of 256 and >= the padded S_q): no ragged tile, no generic path -- and fewer variants to keep registers for
+        // (their DMA slots carry the NEXT pass's first NBUF - 1 tiles, the first of them its Q rows too)
+        int rt_last;
         if constexpr (RT == 2) {
-          tile_step(t, rt, I2{}, I1{});
-          tile_step(t + 1, nxt(rt), I3{}, I1{});
+          tile_step(t, rt, I2{}, I1{}, I2{});
+          tile_step(t + 1, rt_last = nxt(rt), I3{}, I1{}, I1{});
         } else {
-          tile_step(t, rt, I2{}, I1{});
-          tile_step(t + 1, nxt(rt), I2{}, I1{});
-          tile_step(t + 2, nxt(nxt(rt)), I3{}, I1{});
-          tile_step(t + 3, nxt(nxt(nxt(rt))), I3{}, I2{});
+          tile_step(t, rt, I2{}, I1{}, I0{});
+          tile_step(t + 1, nxt(rt), I2{}, I1{}, I1{});
+          tile_step(t + 2, nxt(nxt(rt)), I3{}, I1{}, I1{});
+          tile_step(t + 3, rt_last = nxt(nxt(nxt(rt))), I3{}, I2{}, I1{});
         }
+        static_assert(C::NBUF - 1 == (RT == 2 ? 2 : 3), "the masked tiles carry exactly the next pass's first NBUF - 1 tiles");
         FA4_STAMP(4);   // seg[4]: the masked tiles
-        drain(I0{}, I2{}, ntiles - 1);
+        drain(I0{}, I2{}, rt_last);
+        rt = rt_last;
       } else {
         // a ragged last tile masks both row blocks element-wise (a tile treats its predecessor as masked too: a plain
         // predecessor carries the neutral threshold)
-        for (; t < ntiles; ++t, rt = nxt(rt)) tile_step(t, rt, I1{}, I1{});
+        for (; t < ntiles; ++t, rt = nxt(rt)) tile_step(t, rt, I1{}, I1{}, I0{});
+        rt = rt == 0 ? C::NBUF - 1 : rt - 1;   // the last tile's slot
         // the set of the last block: NKB is even, so it is always set 1 -> the drain's "previous" set is 1
         FA4_STAMP(4);
-        drain(I0{}, I1{}, ntiles - 1);
+        drain(I0{}, I1{}, rt);
       }
       FA4_STAMP(5);   // seg[5]: drain
 
@@ -575,19 +677,17 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       }
       FA_LDS int* flag = (FA_LDS int*)(smem + C::FLAG_OFF);
       if (attempt == 0 && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *flag = 1;
-      __builtin_amdgcn_s_waitcnt(0x0070);   // every DMA of the pass retired (the ring is reused below), the flag written
+      // the flag written, and every DMA retired but (CONT) the next pass's tiles 1 .. NBUF - 2, which target slots other
+      // than the one the epilogue stages in (the last tile's, rt): its tile 0 and its Q rows have landed for the next pass
+      if (CONT) __builtin_amdgcn_s_waitcnt(0x0070 | (((C::NBUF - 2) * 2 * C::PIECES) & 15) | ((((C::NBUF - 2) * 2 * C::PIECES) >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0070);
       __syncthreads();
       const int redo = __builtin_amdgcn_readfirstlane(*flag);
-      FA4_STAMP(6);   // seg[6]: end-of-pass check (row sums, flag, barrier with every DMA retired)
+      FA4_STAMP(6);   // seg[6]: end-of-pass check (row sums, flag, barrier)
       if (!redo) {
-        if (pass + 1 < npass) {   // the next pass streams the same K/V tiles: on their way during this epilogue
-#pragma unroll
-          for (int t = 0; t < C::NBUF - 1; ++t) fetch_tile(t);
-          primed = true;
-        }
-        // ---- epilogue: O = o / l, staged in ring slot NBUF - 1 (K image for waves 0-1, V image for waves 2-3), which the
-        // next pass's DMA reaches only after its first commit -- every wave is past its epilogue by then
-        FA_LDS char* stage = smem + (wave >> 1) * C::V_BASE + (C::NBUF - 1) * C::TILE_BYTES + (wave & 1) * 32 * C::ROWB;
+        // ---- epilogue: O = o / l, staged in the last tile's ring slot (K image for waves 0-1, V image for waves 2-3), which
+        // the next pass's DMA reaches only after its first commit -- every wave is past its epilogue by then
+        FA_LDS char* stage = smem + (wave >> 1) * C::V_BASE + rt * C::TILE_BYTES + (wave & 1) * 32 * C::ROWB;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const float inv = lt[rb] > 0.f ? 1.0f / lt[rb] : 0.f;
@@ -595,9 +695,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
           if (h == 0)
             buf_store_f32(rl, (qrow(rb) + r) * 4, mrow[rb] * (FOLD ? kLn2 : p.scale) + __builtin_logf(lt[rb]));
         }
-        FA4_STAMP(7);   // seg[7]: epilogue (and the next pass's ring priming)
+        FA4_STAMP(7);   // seg[7]: epilogue
+        primed = has_next;
+        r0 = rt + 1 == C::NBUF ? 0 : rt + 1;   // where the masked tiles put the next pass's tile 0
         break;
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // (the next pass's tiles still in flight: the second attempt restarts the ring)
       __syncthreads();
       if (tid == 0) {
         *flag = 0;   // (ordered before the second attempt's check by the barriers of its sweep)
@@ -606,11 +709,21 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
 #endif
       }
     }  // attempt
-  }  // pass
+    // ---- on to the pair's second pass, or to the workgroup's next item ----
+    if (more_pass) {
+      ++pass;
+    } else {
+      item += gridDim.x;
+      if (item >= n_items) break;
+      wk = nwk_item;
+      nwk_item = decode(min(item + (int)gridDim.x, n_items - 1));
+      pass = 0;
+    }
+  }  // passes and items
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {
     unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 16;
-    for (int i = 0; i < 8; ++i) d[i] = seg[i];
+    for (int i = 0; i < 12; ++i) d[i] = seg[i];
     d[12] = npass_;
     d[13] = ntile_;
     unsigned long long clk1_, rt1_;
@@ -624,7 +737,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
 template <int D, typename T, bool CAUSAL>
 static hipError_t launch4(const FwdParams& p, hipStream_t s) {
   using C = Fwd4Cfg<D>;
-  const int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
+  int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
+  if constexpr (CAUSAL) {   // persistent: one workgroup per CU, a multiple of 8 (fa_fwd4_kernel: the work list)
+    static std::atomic<int> cus{0};
+    int n = cus.load(std::memory_order_relaxed);
+    if (n == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+      n -= n % 8;
+      cus.store(n, std::memory_order_relaxed);
+    }
+    if (grid > n) grid = n;
+  }
   auto kern = fa_fwd4_kernel<D, T, CAUSAL>;
   static std::atomic<unsigned long long> opted_in{0};   // per template instance: devices already opted in
   if (hipError_t e = opt_in_lds((const void*)kern, C::LDS_BYTES, opted_in)) return e;
@@ -637,6 +761,8 @@ static hipError_t launch4(const FwdParams& p, hipStream_t s) {
 hipError_t launch_fwd_v4(FwdParams p, int D, int dtype, int causal, hipStream_t s) {
   p.nq_tiles = (p.Sq + 255) / 256;
   p.pair = causal != 0;
+  p.div_per_bh = make_fastdiv(p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles);
+  p.div_h = make_fastdiv(p.H);
 #define FA_GO(DD, TT) (causal ? launch4<DD, TT, true>(p, s) : launch4<DD, TT, false>(p, s))
   if (D == 64) return dtype == 1 ? FA_GO(64, BF16) : FA_GO(64, FP16);
   if (D == 128) return dtype == 1 ? FA_GO(128, BF16) : FA_GO(128, FP16);

@@ -19,6 +19,21 @@ inline TensorLayout contiguous_layout(int H, int S, int D) {
   return TensorLayout{(long long)H * S * D * 2, (long long)S * D * 2, D * 2};
 }
 
+// Division of a work-list index by a launch constant (slices per (batch, head), heads): the persistent kernels decode an
+// item per pass, and hipcc's 32-bit division is ~40 instructions that bounce between the scalar and the vector unit
+// (stamps: ~1k cycles per decoded item, fa_fwd_v4.hip).  Round-up multiply-shift, exact for 0 <= n < 2^31, 1 <= d < 2^31:
+// l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, n / d = (mulhi(m, n) + n) >> l.
+struct FastDiv {
+  unsigned m;
+  int l;
+  __device__ __forceinline__ int div(int n) const { return (int)((__umulhi(m, (unsigned)n) + (unsigned)n) >> l); }
+};
+inline FastDiv make_fastdiv(int d) {
+  int l = 0;
+  while ((1ll << l) < d) ++l;
+  return FastDiv{(unsigned)((((1ull << l) - (unsigned long long)d) << 32) / (unsigned long long)d + 1), l};
+}
+
 // Variable-length ("varlen") launches: Q/K/V/O and the gradients are PACKED [total tokens, H, D] tensors, sequence b
 // owns rows [cu[b], cu[b+1]) (cu_seqlens_q / cu_seqlens_k, int32, batch + 1 entries, device memory); LSE and delta are
 // [H, total_q].  The kernels then take S_q / S_k and every base pointer per (batch, head) from the cu arrays; the grid
@@ -74,6 +89,7 @@ struct FwdParams {
   int nq_tiles;  // filled by the launcher
   void* dbg;     // diagnostic builds (-DFA_STAMPS) only: cycle-stamp buffer, else unused
   int pair;      // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
+  FastDiv div_per_bh, div_h;   // filled by the family-4 launcher: work-list index -> slice -> (batch, head)
   TensorLayout lq, lk, lv;  // K and V share their row stride (checked by the C ABI)
   TensorLayout lo;          // output O: contiguous [B, H, S, D] for the reference's launch, strided (fa_fwd_strided), packed rows for varlen
   long long lse_sb, lse_sh; // LSE element strides per batch / head (rows of one (batch, head) are contiguous)
@@ -100,6 +116,7 @@ struct BwdParams {
   int n_tiles;      // filled by the launcher
   void* dbg;        // diagnostic builds (-DFA_STAMPS) only
   int pair;         // filled by the launcher: causal workgroups take tile pairs (i, n-1-i)
+  FastDiv div_per_bh, div_h;   // filled by the family-4 launchers: work-list index -> slice -> (batch, head)
   TensorLayout lq, lk, lv, ldo;  // K and V share their row stride (checked by the C ABI)
   TensorLayout lo, ldq, ldk, ldv;  // O (input of the dQ kernel) and the gradient outputs: contiguous, strided, or packed rows (varlen)
   // bf16 scale fold, optional workspace (include/mi355fa.h mi355fa_opts.q_scaled): the dQ kernel writes the Q it actually

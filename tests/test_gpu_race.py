@@ -1,0 +1,83 @@
+"""Race tests (run with -m gpu on an MI355X): every one-wave-per-SIMD kernel (schedule family 4) is launched many times
+on FIXED inputs at the headline shape, each launch preceded by fa_debug_poison (NaN patterns in every CU's LDS and in every
+vector / accumulator register), and every result must equal the first one bit for bit.
+
+Why this exists: these kernels order their LDS-DMA pieces, row-constant loads and stores with COUNTED vmcnt waits.  A count
+that is off by one request is invisible to the parity tests -- the load it fails to cover has almost always landed -- and
+invisible to a test that repeats one launch without poison, because LDS and registers still hold the previous launch's
+(identical) data.  Round 4's dK/dV family 4 published a row constant ahead of its load once in ~30 launches under load;
+parity, fuzz and family-vs-family tests were green.  tools/race_stress.py is the same check with more runs and shapes.
+"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, H, S, D = 4, 32, 4096, 64   # BASELINE configs[2]: 2048 work items, 8 passes per persistent workgroup
+RUNS = 120
+
+
+def _lib():
+    import _mi355fa as fa
+    lib = fa.lib
+    lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+    lib.fa_debug_force_impl.restype = None
+    lib.fa_debug_pick.argtypes = [ctypes.c_int] * 8
+    lib.fa_debug_pick.restype = ctypes.c_int
+    lib.fa_debug_poison.argtypes = [ctypes.c_void_p]
+    lib.fa_debug_poison.restype = ctypes.c_int
+    return lib
+
+
+def _bits(a):
+    return a.view(torch.int16 if a.dtype != torch.float32 else torch.int32)
+
+
+@pytest.mark.parametrize("causal", [1, 0], ids=["causal", "full"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("kern", ["fwd", "dq", "dkv"])
+def test_family4_results_do_not_change_from_launch_to_launch(kern, dtype, causal):
+    lib = _lib()
+    code = 1 if dtype == torch.bfloat16 else 0
+    P = lambda t: t.data_ptr()
+    torch.manual_seed(S + causal)
+    Q, K, V, dO = (torch.randn(B, H, S, D, device="cuda", dtype=dtype) for _ in range(4))
+    st = torch.cuda.current_stream().cuda_stream
+    sc = D ** -0.5
+    O = torch.empty_like(Q)
+    LSE = torch.empty(B, H, S, device="cuda")
+    dq0, delta0 = torch.empty_like(Q), torch.empty_like(LSE)
+    try:
+        lib.fa_debug_force_impl(0, 0, 0)
+        assert lib.fa_fwd(P(Q), P(K), P(V), P(O), P(LSE), B, H, S, S, D, code, causal, sc, st) == 0
+        assert lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(dq0), P(delta0), B, H, S, S, D, code, causal, sc, st) == 0
+        lib.fa_debug_force_impl(4 if kern == "fwd" else 0, 4 if kern == "dq" else 0, 4 if kern == "dkv" else 0)
+        if lib.fa_debug_pick({"fwd": 0, "dq": 1, "dkv": 2}[kern], D, code, causal, B, H, S, S) != 4:
+            pytest.skip("family 4 does not take this launch (fa_kernels.h)")
+        shape0, shape1 = (Q, LSE) if kern != "dkv" else (K, V)
+        a0, a1, b0, b1 = torch.empty_like(shape0), torch.empty_like(shape1), torch.empty_like(shape0), torch.empty_like(shape1)
+
+        def run(x0, x1):
+            x0.fill_(float("nan"))
+            x1.fill_(float("nan"))
+            assert lib.fa_debug_poison(st) == 0
+            if kern == "fwd":
+                assert lib.fa_fwd(P(Q), P(K), P(V), P(x0), P(x1), B, H, S, S, D, code, causal, sc, st) == 0
+            elif kern == "dq":
+                assert lib.fa_bwd_dq(P(Q), P(K), P(V), P(O), P(dO), P(LSE), P(x0), P(x1), B, H, S, S, D, code, causal, sc, st) == 0
+            else:
+                assert lib.fa_bwd_dkv(P(Q), P(K), P(V), P(dO), P(LSE), P(delta0), P(x0), P(x1), B, H, S, S, D, code, causal, sc, st) == 0
+
+        run(a0, a1)
+        torch.cuda.synchronize()
+        assert not torch.isnan(a0.float()).any() and not torch.isnan(a1.float()).any()
+        changed = []
+        for i in range(RUNS):
+            run(b0, b1)
+            if not (torch.equal(_bits(a0), _bits(b0)) and torch.equal(_bits(a1), _bits(b1))):
+                changed.append(i)
+        assert not changed, "launches %s of %d gave other bits than the first" % (changed[:8], RUNS)
+    finally:
+        lib.fa_debug_force_impl(0, 0, 0)

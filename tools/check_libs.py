@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bitwise comparison of the three kernels' outputs between two builds of libmi355fa.so (A/B variants that must not
-change results).  usage: check_libs.py ab/a.so ab/b.so"""
+change results).  usage: check_libs.py ab/a.so ab/b.so [--force F,Q,K]   (schedule families forced in both, 0 = the table)"""
 import ctypes
 import os
 import sys
@@ -22,10 +22,16 @@ def load(path):
 
 
 A, B_ = load(sys.argv[1]), load(sys.argv[2])
+if "--force" in sys.argv:
+    fam = [int(x) for x in sys.argv[sys.argv.index("--force") + 1].split(",")]
+    for lib in (A, B_):
+        lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+        lib.fa_debug_force_impl(*fam)
 P = lambda t: t.data_ptr()
 bad = 0
 for (B, H, Sq, Sk, D) in [(1, 2, 128, 128, 64), (2, 2, 320, 320, 64), (1, 2, 500, 500, 64), (1, 2, 333, 777, 64), (1, 2, 777, 333, 64),
-                          (2, 3, 1024, 1024, 64), (4, 32, 4096, 4096, 64), (1, 2, 640, 640, 128), (2, 16, 2048, 2048, 128)]:
+                          (2, 3, 1024, 1024, 64), (4, 32, 4096, 4096, 64), (3, 5, 1280, 1280, 64), (1, 2, 640, 640, 128), (2, 16, 2048, 2048, 128),
+                          (3, 7, 768, 1024, 128)]:
     for dt, code in ((torch.bfloat16, 1), (torch.float16, 0)):
         for causal in (0, 1):
             torch.manual_seed(Sq + Sk)

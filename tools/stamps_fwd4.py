@@ -24,6 +24,8 @@ c, sc = int(causal), D ** -0.5
 lib.fa_debug_force_impl(4, 0, 0)
 nqt = S // 256
 nwg = (nqt // 2 if causal else nqt) * B * H
+if causal and "--not-persistent" not in sys.argv:   # causal launches are persistent: one workgroup per CU (round 4)
+    nwg = min(nwg, torch.cuda.get_device_properties(0).multi_processor_count // 8 * 8)
 dbg = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(12):
@@ -36,8 +38,9 @@ ms = e0.elapsed_time(e1)
 d = dbg.cpu().view(nwg, 4, 16).double()
 names = ["pass prologue: Q fragments, ring primed, tile 0 landed", "scout block + row constants", "pipeline fill",
          "plain tiles", "masked tiles (the 256 keys level with the query tile)", "drain",
-         "end-of-pass check (row sums, flag, barrier)", "epilogue (+ priming the next pass's ring)"]
-tot = d[:, :, :8].sum()
+         "end-of-pass check (row sums, flag, barrier)", "epilogue (+ priming the next pass's ring)",
+         "loop bookkeeping: next item decoded, descriptors", "an unprimed pass's requests (Q rows, first tiles)", "Q fragments", "-"]
+tot = d[:, :, :12].sum()
 passes, tiles = d[:, :, 12].sum(), d[:, :, 13].sum()
 bn = 128 if D == 64 else 64
 print("%s D=%d: kernel %.3f ms; passes per wave %.2f, plain tiles (%d keys) per pass %.2f; stamped cycles per pass %.0f; per plain tile %.0f (MFMA pipe: %d)"
