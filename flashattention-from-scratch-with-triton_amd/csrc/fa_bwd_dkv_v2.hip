@@ -259,15 +259,40 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
           pacc[4 * g + j] = d[j];
         }
       }
+      if constexpr (D == 128) {   // VGPR-form asm chains started from the row constants (tile_pipelined says why)
+        f32x16 sv, pv;
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
-        sacc = T::mfma(a, kf[ks], sacc);
-      }
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const u32x4 a = lds_read16(qbp + row_off[ks]);
+          if (ks == 0) {
+            if constexpr (FOLD) T::mfma_v_first(sv, a, __builtin_bit_cast(u32x4, kf[0]), sacc);
+            else T::mfma_v_first0(sv, a, __builtin_bit_cast(u32x4, kf[0]));
+          } else {
+            T::mfma_v_acc(sv, a, __builtin_bit_cast(u32x4, kf[ks]));
+          }
+          if (FOLD && ks == 1) keep_live(sacc);   // a C operand is read over the MFMA's passes (tools/mfma_lint.py R2)
+        }
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        vec8 a = as_vec8<T>(lds_read16(dbp + row_off[ks]));
-        pacc = T::mfma(a, vf[ks], pacc);
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const u32x4 a = lds_read16(dbp + row_off[ks]);
+          if (ks == 0) T::mfma_v_first(pv, a, __builtin_bit_cast(u32x4, vf[0]), pacc);
+          else T::mfma_v_acc(pv, a, __builtin_bit_cast(u32x4, vf[ks]));
+          if (ks == 1) keep_live(pacc);
+        }
+        settle_mfma(sv, pv);   // asm MFMA results -> VALU readers (hipcc pads nothing around asm)
+        sacc = sv;
+        pacc = pv;
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          vec8 a = as_vec8<T>(lds_read16(qbp + row_off[ks]));
+          sacc = T::mfma(a, kf[ks], sacc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          vec8 a = as_vec8<T>(lds_read16(dbp + row_off[ks]));
+          pacc = T::mfma(a, vf[ks], pacc);
+        }
       }
       FA_STAMP(1);  // row-constant + row-fragment reads, S and dP MFMA chains
       // transposed fragments for dV^T / dK^T: issued BEFORE the exp / dS arithmetic (order pinned) so that
@@ -329,25 +354,58 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
       constexpr int P0 = KS, V0 = 2 * KS, K0 = 2 * KS + 2 * DB, NS = 2 * KS + 4 * DB;
       constexpr int EPS = 16 / V0;          // exps per slot under S / dP            (D=64: 2, D=128: 1)
       constexpr int MPS = 16 / (2 * DB);    // dS multiplies (or fmas) per dV (dK) slot (D=64: 4, D=128: 2)
+      // LDS addresses are `per-lane base register (set once per tile, opaque to hipcc) + immediate`.  Left alone, hipcc
+      // hoists every (lane offset + constant) pair out of the tile loop and parks the values in accumulator registers; at
+      // D = 128, where the tile images span 128 KiB (past the 16-bit immediate of ds_read), that was 721 v_add_u32 and a
+      // good part of 768 v_accvgpr_read per 640 MFMAs of the kernel -- 4.2 vector instructions per MFMA, MFMA pipe 49 %
+      // busy (profiles/r04_pmc_summary_d128.txt).  (fa_fwd_v4.hip does the same.)
+      // (D = 64 keeps plain pointer sums: its images fit the immediate, and two workgroups per CU at 256 registers have
+      //  no room for 13 base registers -- they spilled)
+      constexpr bool OB = D == 128;
+      auto ob = [](int x) __attribute__((always_inline)) { return OB ? opaque(x) : x; };
       const FA_LDS char* qt = smem + BUF * C::TILE_BYTES;
       const FA_LDS char* dt = smem + C::DO_BASE + BUF * C::TILE_BYTES;
       const FA_LDS char* rcp = smem + C::ROWC_OFF + BUF * C::ROWC_BYTES;
+      const int lds0 = (int)lds_addr_of(smem);
+      int qb_[KS], db_[KS], tq_[2][DB], td_[2][DB];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qb_[ks] = ob(lds0 + row_off[ks] + BUF * C::TILE_BYTES);
+        db_[ks] = ob(lds0 + row_off[ks] + C::DO_BASE + BUF * C::TILE_BYTES);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          tq_[e][db] = ob(lds0 + tr_off[e][db] + BUF * C::TILE_BYTES);
+          td_[e][db] = ob(lds0 + tr_off[e][db] + C::DO_BASE + BUF * C::TILE_BYTES);
+        }
+      const int rcb = ob(lds0 + C::ROWC_OFF + BUF * C::ROWC_BYTES + 16 * h);
       // operand fragment of slot s of block b (block index QB = the drain pass: only the slots from V0 on exist)
       auto frag = [&](int b, int s) __attribute__((always_inline)) -> vec8 {
-        if (s < V0) {  // row fragments of block b: Q rows (k-steps 0..KS-1), then dO rows
-          const FA_LDS char* base = (s < P0 ? qt : dt) + b * 32 * C::ROWB;
-          return as_vec8<T>(lds_read16(base + row_off[s < P0 ? s : s - P0]));
+        if constexpr (!OB) {
+          if (s < V0) {  // row fragments of block b: Q rows (k-steps 0..KS-1), then dO rows
+            const FA_LDS char* base = (s < P0 ? qt : dt) + b * 32 * C::ROWB;
+            return as_vec8<T>(lds_read16(base + row_off[s < P0 ? s : s - P0]));
+          }
+          const int n = s < K0 ? s - V0 : s - K0;
+          const FA_LDS char* base = (s < K0 ? dt : qt) + (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
+          return lds_read_tr_frag<T>(base + tr_off[0][n >> 1], base + tr_off[1][n >> 1]);
         }
+        if (s < V0)  // row fragments of block b: Q rows (k-steps 0..KS-1), then dO rows
+          return as_vec8<T>(lds_read16(lds_at((s < P0 ? qb_[s] : db_[s - P0]) + b * 32 * C::ROWB)));
         // transposed fragments of block b-1: dO^T (d block n>>1, k-step n&1), then Q^T
         const int n = s < K0 ? s - V0 : s - K0;
-        const FA_LDS char* base = (s < K0 ? dt : qt) + (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
-        return lds_read_tr_frag<T>(base + tr_off[0][n >> 1], base + tr_off[1][n >> 1]);
+        const int imm = (b - 1) * 32 * C::ROWB + (n & 1) * 16 * C::ROWB;
+        if (s < K0) return lds_read_tr_frag<T>(lds_at(td_[0][n >> 1] + imm), lds_at(td_[1][n >> 1] + imm));
+        return lds_read_tr_frag<T>(lds_at(tq_[0][n >> 1] + imm), lds_at(tq_[1][n >> 1] + imm));
       };
       // row constants of block b, group g (registers 4g..4g+3 <-> rows 8g + 4h + 0..3): the accumulators START
       // from them, so the MFMA chains deliver  s*c2 - LSE*log2e  (K is pre-scaled by c2) and  dP - delta
       auto rowc = [&](int b, int g, f32x16& s0, f32x16& p0) __attribute__((always_inline)) {
-        const f32x4 a = *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * g + 4 * h) * 4);
-        const f32x4 d = *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * g + 4 * h) * 4);
+        const f32x4 a = OB ? *(const FA_LDS f32x4*)lds_at(rcb + (32 * b + 8 * g) * 4) : *(const FA_LDS f32x4*)(rcp + (32 * b + 8 * g + 4 * h) * 4);
+        const f32x4 d = OB ? *(const FA_LDS f32x4*)lds_at(rcb + (C::BQ + 32 * b + 8 * g) * 4)
+                           : *(const FA_LDS f32x4*)(rcp + (C::BQ + 32 * b + 8 * g + 4 * h) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           s0[4 * g + j] = a[j];
@@ -363,12 +421,22 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
       static_assert(NS % RD == 0, "ring depth must divide the slot count");
       vec8 fr[RD];                  // operand ring
       f32x16 sacc, pacc;            // this block's accumulators
+      // D = 128: the S and dP chains are VGPR-form asm MFMAs (fa_common.h mfma_v_*), started from the row constants as a
+      // separate C operand.  hipcc's own MFMAs all accumulate in accumulator registers (one form per kernel), and every
+      // score / dP value then costs a v_accvgpr_read before the exp / multiply can touch it: 32 per 32-MFMA block, one
+      // more vector instruction per MFMA in a loop that issues 4.2 of them per MFMA (profiles/r04_pmc_summary_d128.txt).
+      // dV^T / dK^T stay hipcc's: they are only read in the epilogue.  (D = 64: two workgroups per CU, other budget.)
+      constexpr bool VCH = D == 128;
+      f32x16 sC, pC;                // VCH: this block's chain starts (-LSE*log2e | unused, -delta)
       f32x16 nl;                    // exact mode (!FOLD): -LSE*log2e of this block, added by an fma under the dK slots
 #pragma unroll
       for (int s = 0; s < RD; ++s) fr[s] = frag(0, s);
       if constexpr (FOLD) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rowc(0, g, sacc, pacc);
+        for (int g = 0; g < 4; ++g) {
+          if constexpr (VCH) rowc(0, g, sC, pC);
+          else rowc(0, g, sacc, pacc);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -380,9 +448,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
         if constexpr (!FOLD) {
           if (cur) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rowc(b, g, nl, pacc);
+            for (int g = 0; g < 4; ++g) {
+              if constexpr (VCH) rowc(b, g, nl, pC);
+              else rowc(b, g, nl, pacc);
+            }
+            if constexpr (!VCH) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+              for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -391,10 +464,34 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
           const bool active = s < V0 ? cur : prev;
           if (active) {
             const vec8 a = fr[s % RD];
-            if (s < P0) sacc = T::mfma(a, kf[s], sacc);
-            else if (s < V0) pacc = T::mfma(a, vf[s - P0], pacc);
-            else if (s < K0) dvacc[(s - V0) >> 1] = T::mfma(a, as_vec8<T>(pk[(s - V0) & 1]), dvacc[(s - V0) >> 1]);
-            else dkacc[(s - K0) >> 1] = T::mfma(a, as_vec8<T>(sk[(s - K0) & 1]), dkacc[(s - K0) >> 1]);
+            if (s < V0) {
+              if constexpr (VCH) {
+                const u32x4 a4 = __builtin_bit_cast(u32x4, a);
+                if (s == 0) {
+                  if constexpr (FOLD) T::mfma_v_first(sacc, a4, __builtin_bit_cast(u32x4, kf[0]), sC);
+                  else T::mfma_v_first0(sacc, a4, __builtin_bit_cast(u32x4, kf[0]));
+                } else if (s < P0) {
+                  T::mfma_v_acc(sacc, a4, __builtin_bit_cast(u32x4, kf[s < P0 ? s : 0]));
+                } else if (s == P0) {
+                  T::mfma_v_first(pacc, a4, __builtin_bit_cast(u32x4, vf[0]), pC);
+                } else {
+                  T::mfma_v_acc(pacc, a4, __builtin_bit_cast(u32x4, vf[s >= P0 ? s - P0 : 0]));
+                }
+              } else {
+                if (s < P0) sacc = T::mfma(a, kf[s < P0 ? s : 0], sacc);
+                else pacc = T::mfma(a, vf[s >= P0 ? s - P0 : 0], pacc);
+              }
+            } else if (s < K0) {
+              dvacc[(s - V0) >> 1] = T::mfma(a, as_vec8<T>(pk[(s - V0) & 1]), dvacc[(s - V0) >> 1]);
+            } else {
+              dkacc[(s - K0) >> 1] = T::mfma(a, as_vec8<T>(sk[(s - K0) & 1]), dkacc[(s - K0) >> 1]);
+            }
+          }
+          // (an MFMA reads its C operand over its passes and hipcc pads that for its own MFMAs only: a chain-start block
+          //  that is dead after its use would be reused at once -- live one more slot; tools/mfma_lint.py rule R2)
+          if constexpr (VCH) {
+            if (FOLD && cur && s == 1) keep_live(sC);
+            if (cur && s == P0 + 1) keep_live(pC);
           }
           // operand four slots ahead (wraps into the next block's row fragments; none past the last block)
           {
@@ -446,8 +543,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
         }
         if constexpr (FOLD) {
           if (b + 1 < C::QB) {
-            sacc = sn;
-            pacc = pn;
+            if constexpr (VCH) {
+              sC = sn;
+              pC = pn;
+            } else {
+              sacc = sn;
+              pacc = pn;
+            }
           }
         }
       }

@@ -54,7 +54,10 @@ struct BF16 {
 struct FP16 {
   typedef f16x8 vec8;
   typedef _Float16 elem;
-  static constexpr bool kFoldScale = false;
+#ifndef FA_FP16_FOLD   // A/B hook (round 4): fp16 with the scale folded like bf16
+#define FA_FP16_FOLD 0
+#endif
+  static constexpr bool kFoldScale = FA_FP16_FOLD != 0;
   static FA_DEVINL f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }

@@ -170,14 +170,15 @@ std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor
     dK = g.select(0, 0);
     dV = g.select(0, 1);
   }
-  Tensor delta = torch::empty({B, H, Sq}, Q.options().dtype(at::kFloat));
+  // ONE scratch allocation: delta [B, H, S_q] fp32 and, bf16, behind it (256-byte aligned) the Q rows the dQ launch
+  // multiplied, left for the dK/dV launch (mi355fa_opts.q_scaled) -- at the small end of the reference's grid a step is
+  // host-bound and every allocation is ~1 us of it (profiles/r03_small_trace.txt)
+  const int64_t delta_bytes = B * H * Sq * 4, qs_off = (delta_bytes + 255) & ~(int64_t)255;
+  Tensor scratch = torch::empty({qs_off + (dt == MI355FA_BF16 ? B * H * Sq * D * 2 : 0)}, Q.options().dtype(at::kByte));
+  float* delta = (float*)scratch.data_ptr();
   Strides3 sq(Q), sk(K), sv(V), so(O), sdo(dO), sdq(dQ), sdk(dK), sdv(dV);
   mi355fa_opts x = make_opts(p_drop, seed, offset);
-  Tensor qs;  // bf16: the dQ launch leaves the Q rows it multiplied here for the dK/dV launch (mi355fa_opts.q_scaled)
-  if (dt == MI355FA_BF16) {
-    qs = torch::empty({B, H, Sq, D}, Q.options());
-    x.q_scaled = qs.data_ptr();
-  }
+  if (dt == MI355FA_BF16) x.q_scaled = (char*)scratch.data_ptr() + qs_off;
   x.q_strides = sq.ptr;
   x.k_strides = sk.ptr;
   x.v_strides = sv.ptr;
@@ -189,11 +190,11 @@ std::tuple<Tensor, Tensor, Tensor> backward_launch(const Tensor& Q, const Tensor
   void* st = current_stream(Q);
   const float scale = (float)(1.0 / std::sqrt((double)D));
   check_rc(fa_bwd_dq_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
-                        dQ.data_ptr(), (float*)delta.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
+                        dQ.data_ptr(), delta, (int)B, (int)H, (int)Sq, (int)Sk, (int)D, dt, causal ? 1 : 0,
                         scale, &x, st),
            "fa_bwd_dq");
   check_rc(fa_bwd_dkv_ex(Q.data_ptr(), K.data_ptr(), V.data_ptr(), dO.data_ptr(), (const float*)LSE.data_ptr(),
-                         (const float*)delta.data_ptr(), dK.data_ptr(), dV.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D,
+                         (const float*)delta, dK.data_ptr(), dV.data_ptr(), (int)B, (int)H, (int)Sq, (int)Sk, (int)D,
                          dt, causal ? 1 : 0, scale, &x, st),
            "fa_bwd_dkv");
   return {dQ, dK, dV};

@@ -14,7 +14,7 @@ libs = [a for a in sys.argv[3:] if a.endswith(".so")]
 path = libs[0] if libs else "flashattention-from-scratch-with-triton_amd/libmi355fa.so"
 runs = int(arg("--runs", "300"))
 B, H, S = (int(x) for x in arg("--shape", "4,32,4096").split(","))
-D = 64
+D = int(arg("--dim", "64"))
 poison, with_dq = "--poison" in sys.argv, "--with-dq" in sys.argv
 only, only_c = arg("--only", ""), arg("--causal", "")
 lib = ctypes.CDLL(os.path.join(ROOT, path))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-segment cycle shares of a -DFA_STAMPS build of the dK/dV kernel (diagnostic only)."""
+"""Per-segment cycle shares of a -DFA_STAMPS build of the dK/dV kernel, schedule family 2 (diagnostic only).
+usage: stamps_dkv.py [--non-causal] [--dim 128]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flashattention-from-scratch-with-triton_amd"))
@@ -10,7 +11,9 @@ for name, (res, args) in host.SIGNATURES.items():
     fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
 lib.fa_debug_set_buffer.argtypes = [ctypes.c_void_p]
 causal = "--non-causal" not in sys.argv
-B, H, S, D = 4, 32, 4096, 64
+B, H, S, D = 4, 32, 4096, (int(sys.argv[sys.argv.index("--dim") + 1]) if "--dim" in sys.argv else 64)
+lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
+lib.fa_debug_force_impl(0, 0, 2)
 torch.manual_seed(0)
 Q, K, V, dO = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(4))
 O = torch.empty_like(Q); LSE = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
