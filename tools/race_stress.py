@@ -26,6 +26,7 @@ if poison:
     lib.fa_debug_poison.argtypes = [ctypes.c_void_p]
 P = lambda t: t.data_ptr()
 bits = lambda a: a.view(torch.int16 if a.dtype != torch.float32 else torch.int32)
+print("GPU: %s, uuid %s" % (torch.cuda.get_device_name(0), getattr(torch.cuda.get_device_properties(0), "uuid", "?")))
 bad = 0
 for dt, code in ((torch.bfloat16, 1), (torch.float16, 0)):
     if only and only != ("bf16" if code else "fp16"):
