@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Bitwise comparison of two schedule families of one kernel (same maths, same rounding points, same accumulation
-order => identical bits) over a list of shapes, through the C ABI.  usage: check_family.py {fwd|dq|dkv} A B"""
+order => identical bits) over a list of shapes, through the C ABI.  usage: check_family.py {fwd|dq|dkv} A B [--lib ab/variant.so] [--reordered-causal]
+(--lib: check a variant build without replacing the product library)"""
 import ctypes
 import os
 import sys
@@ -16,6 +17,12 @@ kern, fa_, fb_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 # then differ by fp32 summation order -- at most one unit in the last place of the 16-bit output on a small share of elements
 REORDERED = "--reordered-causal" in sys.argv
 lib = host.lib
+if "--lib" in sys.argv:
+    lib = ctypes.CDLL(os.path.join(ROOT, sys.argv[sys.argv.index("--lib") + 1]))
+    for name, (res, args) in host.SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
 lib.fa_debug_force_impl.argtypes = [ctypes.c_int] * 3
 SHAPES = [(1, 2, 64, 64), (1, 2, 128, 128), (2, 3, 192, 192), (1, 2, 256, 256), (2, 2, 320, 320), (1, 2, 448, 448),
           (1, 1, 512, 512), (2, 2, 1024, 1024), (1, 2, 500, 500), (1, 2, 77, 333), (1, 2, 333, 77), (1, 1, 129, 65),

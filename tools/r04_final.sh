@@ -33,6 +33,7 @@ for D in 64 128; do for dt in bf16 fp16; do
 done; done
 echo sweep done
 python3 tools/small_shapes.py 2>&1 | grep -v amdgpu.ids > $O/small_shapes.txt
+{ for S in 512 1024 2048; do python3 tools/graph_step.py 4 8 $S 64; python3 tools/graph_step.py 4 8 $S 64 fp16; done; } 2>&1 | grep -v amdgpu.ids > $O/graph_step_small.txt
 echo small done
 bash tools/profile_round.sh r04 > gpurun_out/r04_profile_round.log 2>&1
 echo bundle done
