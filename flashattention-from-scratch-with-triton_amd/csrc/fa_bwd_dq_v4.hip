@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.delta + b_ * p.lse_sb + h_ * p.lse_sh, (unsigned)Sq * 4);
 
   for (int pass = 0; pass < npass; ++pass) {
+#ifndef FA_STAMPS_ITER
+    FA4Q_STAMP(9);    // seg[9]: loop bookkeeping (item decode, descriptors) since the end of the previous epilogue
+#endif
     // lane coordinates re-derived per pass (fa_common.h lane_id_now): nothing lane-dependent stays live across passes
     const int lane = lane_id_now(), r = lane & 31, h = lane >> 5;
     const int q0_wg = tile_of(wk, pass) * C::BM;
@@ -254,6 +257,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     if (!staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (FOLD && p.qs) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifndef FA_STAMPS_ITER
+    FA4Q_STAMP(10);   // seg[10]: lane addresses, the wait for the staged rows
+#endif
     // the ring: tiles 0 and 1 now (their address-unit time runs under the arithmetic below); tile 2's first half follows once
     // this wave has consumed the O rows that sit in its part of slot b2, the second half rides in the first tile step
 #pragma unroll

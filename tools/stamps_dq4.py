@@ -53,11 +53,11 @@ for i, n in enumerate(names):
     print("  %-70s %5.1f%% of wave lifetime  %8.0f cycles per pass" % (n, 100 * d[:, :, i].sum() / life, d[:, :, i].sum() / passes))
 for i, n in ((5, "prologue: ring primed (20 LDS-DMA pieces issued)"), (6, "prologue: Q / dO / O fetched, delta, scale, pinned"), (7, "prologue: first barrier (vmcnt(0))")):
     print("  %-70s %5.1f%% of wave lifetime  %8.0f cycles per pass" % (n, 100 * d[:, :, i].sum() / life, d[:, :, i].sum() / passes))
-if d[:, :, 9].sum() > 0:
-    for i, n in ((12, "first pass: kernel entry to the first load"), (13, "second pass: top of the pass to the first load"), (9, "first pass: 26 loads issued"), (5, "first pass: 20 LDS-DMA pieces issued"), (11, "second pass: 26 loads issued"), (10, "second pass: 20 LDS-DMA pieces issued")):
-        print("    %-68s %8.0f cycles per wave" % (n, d[:, :, i].sum() / (nwg * 4)))
+if d[:, :, 9].sum() > 0 and d[:, :, 16].sum() == 0 and not DKV:
+    for i, n in ((9, "  of the prologue: loop bookkeeping (item decode, descriptors)"), (10, "  of the prologue: lane addresses, wait for the staged rows")):
+        print("  %-70s %5.1f%% of wave lifetime  %8.0f cycles per pass" % (n, 100 * d[:, :, i].sum() / life, d[:, :, i].sum() / passes))
 print("  unmasked tile: %.0f stamped cycles (96 MFMAs = 3072 matrix cycles)" % (d[:, :, 1].sum() / tiles))
-if d[:, :, 8:17].sum() > 0:
+if d[:, :, 16].sum() > 0:   # a -DFA_STAMPS_ITER build (seg[16] = the commit)
     for i in range(8):
         print("    iteration %d (key block %d, row block %d)%s  %6.0f cycles per tile" % (
             i, i >> 1, i & 1, " without its commit" if i == 7 else "", d[:, :, 8 + i].sum() / tiles))
