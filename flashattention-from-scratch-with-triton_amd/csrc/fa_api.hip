@@ -155,6 +155,15 @@ int fa_debug_pick(int kernel, int D, int dtype, int causal, int B, int H, int S_
   return fa::pick_dkv_impl(fa::g_force_dkv, D, dtype, B, H, S_q, S_k, causal != 0);
 }
 
+// Not part of the public header: the work-list division of the persistent kernels (fa_kernels.h FastDiv) evaluated on the
+// host exactly as the device evaluates it -- multiplier and shift from make_fastdiv(d), quotient = (mulhi(m, n) + n) >> l --
+// so that a CPU test can sweep it against n / d.
+int fa_debug_fastdiv(int n, int d) {
+  const fa::FastDiv f = fa::make_fastdiv(d);
+  const unsigned hi = (unsigned)(((unsigned long long)f.m * (unsigned)n) >> 32);
+  return (int)((hi + (unsigned)n) >> f.l);
+}
+
 // Not part of the public header: diagnostic hook used by tools/stamps*.py with -DFA_STAMPS builds; in the product library the
 // family-4 forward counts, in the buffer's first word, the passes that took their exact second attempt (tests).
 void fa_debug_set_buffer(void* p) { g_dbg = p; }

@@ -309,3 +309,27 @@ def test_product_path_does_not_touch_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(PKG, f)).read()
             assert "fa_oracle" not in src and "oracle" not in src.lower().replace("# oracle", ""), f
+
+
+def test_work_list_division_is_exact():
+    """fa_kernels.h FastDiv (round 4): the persistent kernels decode a work item with a multiply-shift division by launch
+    constants (slices per (batch, head), heads).  Exact for every 0 <= n < 2^31 and 1 <= d < 2^31 by construction; swept here
+    over the divisors a launch can produce and the numerators around every multiple, plus random pairs."""
+    import ctypes
+    import random
+    import _mi355fa as fa
+    f = fa.lib.fa_debug_fastdiv
+    f.argtypes = [ctypes.c_int, ctypes.c_int]
+    f.restype = ctypes.c_int
+    rng = random.Random(0)
+    ds = list(range(1, 130)) + [255, 256, 257, 1000, 4095, 4096, 4097, 65535, 65536, 65537, 10 ** 6 + 3, 2 ** 30, 2 ** 31 - 1]
+    for d in ds:
+        ns = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31 - d, 2 ** 30}
+        ns |= {k * d + e for k in (3, 7, 1000, (2 ** 31 - 1) // d) for e in (-1, 0, 1)}
+        ns |= {rng.randrange(2 ** 31) for _ in range(50)}
+        for n in ns:
+            if 0 <= n < 2 ** 31:
+                assert f(n, d) == n // d, (n, d, f(n, d))
+    for _ in range(20000):
+        n, d = rng.randrange(2 ** 31), rng.randrange(1, 2 ** 31)
+        assert f(n, d) == n // d, (n, d)
