@@ -23,6 +23,12 @@
 //     masked path, with a compare + select per element.  Here the mask of the two diagonal blocks is free: their score chains
 //     start from (dead ? -inf : -LSE*log2e).  (Non-causal results are bit-identical to family 3's; causal ones differ by
 //     the fp32 summation order only.)
+//   * Causal launches are PERSISTENT and a pass stages the NEXT pass's resident K / V rows through LDS from inside its
+//     diagonal phase, its first two tiles and first row constant from in front of its epilogue (fa_bwd_dq_v4.hip says why).
+// ORDER OF REQUESTS (the invariant every counted wait below relies on; round 4 broke it once, tools/race_stress.py found it):
+// a commit requests the NEXT row constant first, then the Q pairs of the tile two ahead, then (next iteration) its dO pairs --
+// so that the following commit's vmcnt(8) leaves exactly those eight pieces in flight and the row constant, older, has
+// landed.  The pass prologue issues its requests in the same order.
 #include <stdlib.h>
 
 #include <type_traits>

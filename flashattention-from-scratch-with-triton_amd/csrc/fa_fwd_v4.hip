@@ -24,6 +24,11 @@
 //     pack per MFMA; D = 128: one exp and add per MFMA), each closed by sched_barrier(0);
 //   * the per-tile commit (counted vmcnt, s_barrier) sits inside the tile's last iteration; K/V tiles arrive by LDS-DMA
 //     into a ring of three (D = 64, 128-key tiles) or four (D = 128, 64-key tiles) buffers, one to two tiles ahead.
+// Round 4, causal launches: PERSISTENT workgroups (one per CU walks the work list) and a K/V ring that runs on from pass to
+// pass -- the LDS-DMA slots of a pass's last NBUF - 1 tile steps fetch the NEXT pass's first tiles (they used to fetch past
+// the end), at D = 64 together with its Q rows, staged through LDS behind the ring and read back as ds_read_b128 fragments;
+// the work-list decode is a multiply-shift (fa_kernels.h FastDiv).  A pass that follows another starts without a memory
+// wait and without a barrier of its own (the previous end-of-pass check held it).
 // Causal: workgroups take the query-tile pair (nq-1-i, i).  A wave's two row blocks lie in the two HALVES of the 256-row
 // tile (rows 32w.. and 128 + 32w..): of the 256 keys level with the query tile the first 128 are unmasked for every row
 // block 1 and the second 128 invisible to every row block 0 -- those tiles run the same pipeline with a one-compare mask per
