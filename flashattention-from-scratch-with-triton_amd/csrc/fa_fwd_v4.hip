@@ -122,8 +122,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
   // launches are PERSISTENT: a workgroup per CU walks items blockIdx.x, blockIdx.x + gridDim.x, ... (a multiple of 8 keeps a
   // workgroup on one XCD's slice list), because a pass's first K/V tiles and its Q rows are fetched from inside the PREVIOUS
   // pass (CONT / STAGEQ below) and the first pass of an item has no previous pass unless the workgroup stays.
-  constexpr bool CONT = CAUSAL;                // the K/V ring runs on from pass to pass (and from item to item)
-  constexpr bool STAGEQ = CAUSAL && D == 64;   // the next pass's Q rows come through LDS (Fwd4Cfg::QS_OFF)
+  // CONT: the K/V ring runs on from pass to pass (and from item to item).  Causal: always.  Non-causal: when the key range
+  // is whole tiles and at least NBUF - 1 of them (the launcher makes the same test and only then launches persistently) --
+  // the last NBUF - 1 plain tile steps then carry the next item's first tiles as the masked tiles do for a causal pass.
+  const bool CONT = CAUSAL || (p.Sk % C::BN == 0 && p.Sk / C::BN >= C::NBUF - 1);
+  constexpr bool STAGEQ = D == 64;   // the next pass's Q rows come through LDS (Fwd4Cfg::QS_OFF)
   const bool paired = CAUSAL && p.pair;
   const int nq = p.nq_tiles;
   const int per_bh = paired ? (nq + 1) / 2 : nq;
@@ -627,7 +630,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
-      for (; t < nplain; ++t, rt = rt + 1 == C::NBUF ? 0 : rt + 1) tile_step(t, rt, I0{}, I0{}, I0{});
+      // (non-causal CONT: the last NBUF - 1 plain tile steps are written out below, with the next item's requests)
+      const int nloop = (!CAUSAL && CONT) ? nplain - (C::NBUF - 1) : nplain;
+      for (; t < nloop; ++t, rt = rt + 1 == C::NBUF ? 0 : rt + 1) tile_step(t, rt, I0{}, I0{}, I0{});
 #ifdef FA_STAMPS
       FA4_STAMP(3);   // seg[3]: the plain tiles
       ntile_ += nplain;
@@ -664,6 +669,19 @@ __global__ __launch_bounds__(256, 1) void fa_fwd4_kernel(FwdParams p) {
       } else {
         // a ragged last tile masks both row blocks element-wise (a tile treats its predecessor as masked too: a plain
         // predecessor carries the neutral threshold)
+        if (CONT) {   // whole tiles only: no ragged last tile in this branch
+          if constexpr (C::NBUF == 3) {
+            tile_step(t, rt, I0{}, I0{}, I2{});
+            tile_step(t + 1, nxt(rt), I0{}, I0{}, I1{});
+            rt = nxt(nxt(rt));
+          } else {
+            tile_step(t, rt, I0{}, I0{}, I1{});
+            tile_step(t + 1, nxt(rt), I0{}, I0{}, I1{});
+            tile_step(t + 2, nxt(nxt(rt)), I0{}, I0{}, I1{});
+            rt = nxt(nxt(nxt(rt)));
+          }
+          t += C::NBUF - 1;
+        }
         for (; t < ntiles; ++t, rt = nxt(rt)) tile_step(t, rt, I1{}, I1{}, I0{});
         rt = rt == 0 ? C::NBUF - 1 : rt - 1;   // the last tile's slot
         // the set of the last block: NKB is even, so it is always set 1 -> the drain's "previous" set is 1
@@ -743,7 +761,7 @@ template <int D, typename T, bool CAUSAL>
 static hipError_t launch4(const FwdParams& p, hipStream_t s) {
   using C = Fwd4Cfg<D>;
   int grid = (CAUSAL && p.pair ? (p.nq_tiles + 1) / 2 : p.nq_tiles) * p.B * p.H;
-  if constexpr (CAUSAL) {   // persistent: one workgroup per CU, a multiple of 8 (fa_fwd4_kernel: the work list)
+  if (CAUSAL || (p.Sk % C::BN == 0 && p.Sk / C::BN >= C::NBUF - 1)) {   // persistent: one workgroup per CU, a multiple of 8 (fa_fwd4_kernel: the work list, CONT)
     static std::atomic<int> cus{0};
     int n = cus.load(std::memory_order_relaxed);
     if (n == 0) {
