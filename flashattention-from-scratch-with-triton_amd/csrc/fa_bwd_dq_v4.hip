@@ -230,16 +230,6 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       if (g4 < 2) dma_pieces<2>(rk, (unsigned)(lds0 + dst), dma_src + i, soff);
       else dma_pieces<2>(rv, (unsigned)(lds0 + C::V_BASE + dst), dma_src + i, soff);
     };
-    // one piece: j = 0..3 the K pieces, 4..7 the V pieces of this wave's share
-    auto dma_piece1 = [&](int t, int buf, int j) __attribute__((always_inline)) {
-      const int i = j & 3;
-      const int dst = buf * C::TILE_BYTES + ((C::BN / C::NW) * wave + C::RPI * i) * C::ROWB;
-      const int soff = t < ntot ? t * C::BN * kv_rs : C::kOOB;
-      const int v = dma_src[i] + 1024 * (i & 1);
-      if (j < 4) dma_pieces<1>(rk, (unsigned)(lds0 + dst), &v, soff);
-      else dma_pieces<1>(rv, (unsigned)(lds0 + C::V_BASE + dst), &v, soff);
-    };
-
     // ---- resident B operands: Q^T and dO^T fragments of both row blocks; delta (K:210-211, from the rounded O) ----
     // They live in the pinned accumulator registers of fa_common.h (pin_write / MfmaPin): fragment F = 8 rb + ks holds
     // Q^T k-step ks of row block rb, F = 8 rb + 4 + ks its dO^T -- everything else a VGPR-form asm MFMA touches must sit in the
@@ -451,15 +441,21 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
     FA4Q_STAMP(7);   // seg[7]: first barrier
     // ---- fill: the first iteration's "previous block" is neutral (P = 0, dS = 0, zero fragments) ----
     {
+      // A zero hipcc cannot see through (the lane id is below 64).  With constants it folds the neutral block's whole
+      // arithmetic wherever the first tile step is a copy of its own (few tiles: the written-out steps below), keeps the
+      // resulting zero fragments in a scalar register and splats them into place right in front of the asm MFMA that reads
+      // them -- no wait state between (tools/mfma_lint.py rule R1).
+      const unsigned lz = (unsigned)lane_id_now() >> 6;
+      const float lzf = __builtin_bit_cast(float, lz);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        S_[1][i] = i < 14 ? 0.f : -INFINITY;   // exps 0-13 of a block are over when its iteration ends; 14, 15 follow
-        P_[1][i] = 0.f;
+        S_[1][i] = i < 14 ? lzf : -INFINITY + lzf;   // exps 0-13 of a block are over when its iteration ends; 14, 15 follow
+        P_[1][i] = lzf;
       }
 #pragma unroll
-      for (int e = 0; e < 2; ++e) sk[1][e] = u32x4{0u, 0u, 0u, 0u};
+      for (int e = 0; e < 2; ++e) sk[1][e] = u32x4{lz, lz, lz, lz};
 #pragma unroll
-      for (int n = 0; n < 2 * C::DB; ++n) KT[n] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
+      for (int n = 0; n < 2 * C::DB; ++n) KT[n] = as_vec8<T>(u32x4{lz, lz, lz, lz});
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         KR[ks] = lds_read16(smem + b0 * C::TILE_BYTES + row_off[ks]);
@@ -470,37 +466,31 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
 
     FA4Q_STAMP(0);
     // ---- the unmasked tiles: eight block iterations per tile, ring slots rotate ----
-#ifdef FA_DQ4_UNROLL2   // A/B hook
-#pragma unroll 2
-#endif
-    for (int t = 0; t < nfull; ++t) {
+    // Non-causal launches are persistent too, and a pass has no diagonal phase to stage the next item's rows from: they ride
+    // in the LDS-DMA slots of its last three tile steps, which have no tile left to fetch -- SEL 1 (tile nfull - 3): the O rows
+    // into the ring slot of the tile that does not exist (free since this step's commit; three rotations later it is the next
+    // pass's b2), SEL 2: Q and dO into their staging areas, SEL 3: the LSE.  The commits of those steps count the staging
+    // pieces in flight on top of the tile pieces they have always left in flight.
+    const bool nc_stage = !CAUSAL && item + (int)gridDim.x < n_items && nfull >= 3;
+    auto tile_step = [&](int t, auto sel_tag) __attribute__((always_inline)) {
+      constexpr int SEL = decltype(sel_tag)::value;
+      // (defined HERE: a descriptor captured through two levels of closures goes through memory and comes back as a vector)
+      const Stage est = stage_of(nwk_item, 0, SEL != 0);
       int kA[C::KS], kN[C::KS], tA[2][C::DB];
       row_bases(kA, b0 * C::TILE_BYTES);
       row_bases(kN, b1 * C::TILE_BYTES);
       tr_bases(tA, b0 * C::TILE_BYTES);
       // tile t + 2's V pairs ride in the first iteration (its K pairs went out in the previous tile's last one)
       auto hook_first = [&](int s, int phase) __attribute__((always_inline)) {
-        if constexpr (kDq4Mid) {
-        } else if constexpr (kDq4Spread) {
-          if (phase == 1 && s == kDq4SpreadSlot) dma_piece1(t + 2, b2, 0);
-        } else {
+        if constexpr (SEL == 0 || SEL == 1) {
           if (phase == 1 && s == 1) dma_group(t + 2, b2, 2);
           if (phase == 1 && s == 5) dma_group(t + 2, b2, 3);
+        } else if constexpr (SEL == 2) {
+          if (phase == 1 && s == 1) stage_group(est, b2, 0);
+          if (phase == 1 && s == 5) stage_group(est, b2, 1);
+        } else {
+          if (phase == 1 && s == 1) stage_lse(est);
         }
-      };
-      // (spread placement: piece I of tile t + 2 rides in block iteration I, all of them in front of this step's commit)
-      auto hook_mid = [&](auto i_tag) __attribute__((always_inline)) {
-        return [&](int s, int phase) __attribute__((always_inline)) {
-          constexpr int I = decltype(i_tag)::value;
-          if constexpr (kDq4Mid) {
-            if (I == 2 && phase == 1 && s == 1) dma_group(t + 2, b2, 0);
-            if (I == 2 && phase == 1 && s == 7) dma_group(t + 2, b2, 1);
-            if (I == 4 && phase == 1 && s == 1) dma_group(t + 2, b2, 2);
-            if (I == 4 && phase == 1 && s == 7) dma_group(t + 2, b2, 3);
-          } else if constexpr (kDq4Spread) {
-            if (phase == 1 && s == kDq4SpreadSlot) dma_piece1(t + 2, b2, I);
-          }
-        };
       };
       // the commit: tile t + 1 has landed for every wave (vmcnt(8): the eight pieces of tile t + 2 may still fly) and every
       // wave's reads of tile t are complete (the youngest, K^T of its last key block, are four slots old: lgkmcnt(0) is
@@ -509,32 +499,37 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
         if (phase == 0 && s == C::KS) {
           FA4Q_ISTAMP(15);
           asm volatile("" ::: "memory");
-          __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8), lgkmcnt(0)
+          if constexpr (SEL == 2) __builtin_amdgcn_s_waitcnt(0x4070);        // vmcnt(16): 8 + 8 staging pieces younger than tile t + 1
+          else if constexpr (SEL == 3) __builtin_amdgcn_s_waitcnt(0x4072);   // vmcnt(18): nothing follows; staging stays in flight
+          else __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8), lgkmcnt(0)
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           FA4Q_ISTAMP(16);
         }
-        if constexpr (kDq4Mid) {
-        } else if constexpr (kDq4Spread) {
-          if (phase == 1 && s == 1) dma_piece1(t + 2, b2, 7);
-        } else {
+        if constexpr (SEL == 0) {
           if (phase == 1 && s == 5) dma_group(t + 3, b0, 0);
           if (phase == 1 && s == 9) dma_group(t + 3, b0, 1);
+        } else if constexpr (SEL == 1) {   // slot b0 (tile t) is free from the commit above on: the O rows of the next item
+          if (phase == 1 && s == 5) stage_group(est, b0, 4);
+          if (phase == 1 && s == 9) stage_group(est, b0, 5);
+        } else if constexpr (SEL == 2) {
+          if (phase == 1 && s == 5) stage_group(est, b0, 2);
+          if (phase == 1 && s == 9) stage_group(est, b0, 3);
         }
       };
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 0 * C::KBLK, kA, 0, hook_first);
       FA4Q_ISTAMP(8);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 1 * C::KBLK, hook_mid(std::integral_constant<int, 1>{}));
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 1 * C::KBLK, no_hook);
       FA4Q_ISTAMP(9);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 1 * C::KBLK, kA, 0, hook_mid(std::integral_constant<int, 2>{}));
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 1 * C::KBLK, kA, 0, no_hook);
       FA4Q_ISTAMP(10);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 2 * C::KBLK, hook_mid(std::integral_constant<int, 3>{}));
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 2 * C::KBLK, no_hook);
       FA4Q_ISTAMP(11);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 2 * C::KBLK, kA, 0, hook_mid(std::integral_constant<int, 4>{}));
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 2 * C::KBLK, kA, 0, no_hook);
       FA4Q_ISTAMP(12);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 3 * C::KBLK, hook_mid(std::integral_constant<int, 5>{}));
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kA, 3 * C::KBLK, no_hook);
       FA4Q_ISTAMP(13);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 3 * C::KBLK, kA, 0, hook_mid(std::integral_constant<int, 6>{}));
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tA, 3 * C::KBLK, kA, 0, no_hook);
       FA4Q_ISTAMP(14);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tA, 0, kN, 0, hook_last);
       FA4Q_ISTAMP(15);
@@ -545,12 +540,34 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       b0 = b1;
       b1 = b2;
       b2 = bt;
+    };
+    {
+      int t = 0;
+      const int nmain = nc_stage ? nfull - 3 : nfull;
+      for (; t < nmain; ++t) tile_step(t, I0{});
+      if constexpr (!CAUSAL) {
+        if (nc_stage) {
+          tile_step(t, I1{});
+          tile_step(t + 1, std::integral_constant<int, 2>{});
+          tile_step(t + 2, std::integral_constant<int, 3>{});
+        }
+      }
     }
 
     FA4Q_STAMP(1);
     if constexpr (!CAUSAL) {
       pipe_drain(I1{}, I1{});
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the (out-of-range) fetches past the last tile are over before the rings are reused
+      if (nc_stage) {
+        // the O rows went into SEL 1's b0, which three rotations have made b0 again: one more and it is b2, where the next
+        // pass looks for them, and b0 -- where the epilogue below stages dQ -- is the slot of the last tile, which no DMA targets
+        const int bt = b0;
+        b0 = b1;
+        b1 = b2;
+        b2 = bt;
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the (out-of-range) fetches past the last tile are over before the rings are reused
+      }
+      staged = nc_stage;
     } else {
       // ---- the 256 keys level with the query tile: tiles nfull (ring slot b0, landed) and nfull + 1 (b1, in flight) ----
       asm volatile("" ::: "memory");
@@ -669,7 +686,7 @@ template <typename T, bool CAUSAL>
 static hipError_t launch4(const BwdParams& p, hipStream_t s) {
   using C = Dq4Cfg;
   int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
-  if (CAUSAL) {   // persistent: one workgroup per CU walks the work list (a multiple of 8 keeps a workgroup on one XCD's items)
+  {   // persistent: one workgroup per CU walks the work list (a multiple of 8 keeps a workgroup on one XCD's items)
     static std::atomic<int> cus{0};   // CU count of the device first launched on (devices of one node are alike)
     int n = cus.load(std::memory_order_relaxed);
     if (n == 0) {
