@@ -428,19 +428,24 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
     // the neutral "previous block" of the first iteration (P = 0, dS = 0 * 0, packed P / dS and fragments 0) in set PG
     auto pipe_fill = [&](auto pg_tag, int prev_par) __attribute__((always_inline)) {
       constexpr int PG = decltype(pg_tag)::value;
+      // a zero hipcc cannot see through (the lane id is below 64): with constants it folds the neutral block's arithmetic
+      // wherever the first tile step is a written-out copy, keeps the zero fragments in a scalar register and splats them
+      // into place right in front of the asm MFMA that reads them (tools/mfma_lint.py R1; fa_bwd_dq_v4.hip met it)
+      const unsigned lz = (unsigned)lane_id_now() >> 6;
+      const float lzf = __builtin_bit_cast(float, lz);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        S_[PG][i] = i < 11 ? 0.f : -INFINITY;   // exps 0-10 of a block are over when its iteration ends; 11-15 follow
-        P_[PG][i] = 0.f;
-        if (!FOLD) NL[FOLD ? 0 : (prev_par & 1)][i] = 0.f;   // the neutral block's -LSE*log2e (fp16 path)
+        S_[PG][i] = i < 11 ? lzf : -INFINITY + lzf;   // exps 0-10 of a block are over when its iteration ends; 11-15 follow
+        P_[PG][i] = lzf;
+        if (!FOLD) NL[FOLD ? 0 : (prev_par & 1)][i] = lzf;   // the neutral block's -LSE*log2e (fp16 path)
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        pk[PG][e] = u32x4{0u, 0u, 0u, 0u};
-        sk[PG][e] = u32x4{0u, 0u, 0u, 0u};
+        pk[PG][e] = u32x4{lz, lz, lz, lz};
+        sk[PG][e] = u32x4{lz, lz, lz, lz};
       }
 #pragma unroll
-      for (int n = 0; n < 8; ++n) TF[n] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
+      for (int n = 0; n < 8; ++n) TF[n] = as_vec8<T>(u32x4{lz, lz, lz, lz});
     };
 
     // ---- stream position 0 is current: positions 0 and 1 and the first row constant have landed ----
@@ -465,7 +470,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
 
     FA4K_STAMP(0);
     // ---- the unmasked tiles: eight block iterations per tile, ring slots rotate ----
-    for (int i = 0; i < n_main; ++i) {
+    // Non-causal launches are persistent too; with no diagonal phase to stage the next item's K / V rows from, they ride in
+    // the LDS-DMA slots of a pass's last tile steps, which have no tile left to fetch (fa_bwd_dq_v4.hip does the same) --
+    // SEL 1 (position n_main - 3): the V rows into the ring slot of the position that does not exist (free since this step's
+    // commit; three rotations and one more make it the next pass's b2), SEL 2: the K rows into their staging area, SEL 3:
+    // nothing.  SEL 2's commit counts the sixteen staging pieces in flight instead of the eight tile pieces.
+    const bool nc_stage = !CAUSAL && item + (int)gridDim.x < n_items && n_main >= 3;
+    auto tile_step = [&](int i, auto sel_tag) __attribute__((always_inline)) {
+      constexpr int SEL = decltype(sel_tag)::value;
+      // (defined HERE: a descriptor captured through two levels of closures goes through memory and comes back as a vector)
+      const Stage est = stage_of(nwk_item, 0, SEL != 0);
 #ifdef FA_STAMPS
       ++ntile_;
 #endif
@@ -477,23 +491,34 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       const int rcA = opaque(lds0 + C::ROWC_OFF + b0 * C::ROWC_BYTES + 16 * h), rcN = opaque(lds0 + C::ROWC_OFF + b1 * C::ROWC_BYTES + 16 * h);
       // position i + 2's dO pairs ride in the first iteration (its Q pairs went out in the previous tile's last one)
       auto hook_first = [&](int s, int phase) __attribute__((always_inline)) {
-        if (phase == 1 && s == 9) dma_group(i + 2, b2, 2);
-        if (phase == 1 && s == 13) dma_group(i + 2, b2, 3);
+        if constexpr (SEL == 0 || SEL == 1) {
+          if (phase == 1 && s == 9) dma_group(i + 2, b2, 2);
+          if (phase == 1 && s == 13) dma_group(i + 2, b2, 3);
+        } else if constexpr (SEL == 2) {
+          if (phase == 1 && s == 9) stage_group(est, b2, 0);
+          if (phase == 1 && s == 13) stage_group(est, b2, 1);
+        }
       };
       // the commit: position i + 1 and its row constant have landed for every wave (vmcnt(8): the eight pieces of position
       // i + 2 may still fly), every read of position i is issued (slot 4 of the last iteration) and complete (lgkmcnt(0)); the
       // row constants of position i + 1 are published, and the ring slot of position i takes position i + 3
       auto hook_last = [&](int s, int phase) __attribute__((always_inline)) {
         if (phase == 0 && s == 4) {
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          if constexpr (SEL == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // 8 + 8 staging pieces, younger than the row constant
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           rc_publish(RC0{}, b1);
           __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           rc_request(RC0{}, i + 2);
         }
-        if (phase == 1 && s == 9) dma_group(i + 3, b0, 0);
-        if (phase == 1 && s == 13) dma_group(i + 3, b0, 1);
+        if constexpr (SEL == 0) {
+          if (phase == 1 && s == 9) dma_group(i + 3, b0, 0);
+          if (phase == 1 && s == 13) dma_group(i + 3, b0, 1);
+        } else if constexpr (SEL == 1) {   // slot b0 (position i) is free from the commit above on: the V rows of the next item
+          if (phase == 1 && s == 9) stage_group(est, b0, 2);
+          if (phase == 1 && s == 13) stage_group(est, b0, 3);
+        }
       };
       block_iter(I0{}, I0{}, I1{}, I0{}, No{}, No{}, No{}, tA, 0 * C::QBLK, kq, 0, 0, hook_first);
       block_iter(I1{}, I1{}, I0{}, I0{}, No{}, Yes{}, No{}, tA, 0 * C::QBLK, kq, 1 * C::QBLK, rcA + 1 * 32 * 4, no_hook);
@@ -507,11 +532,30 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
       b0 = b1;
       b1 = b2;
       b2 = bt;
+    };
+    {
+      int i = 0;
+      const int nmain = nc_stage ? n_main - 3 : n_main;
+      for (; i < nmain; ++i) tile_step(i, I0{});
+      if constexpr (!CAUSAL) {
+        if (nc_stage) {
+          tile_step(i, I1{});
+          tile_step(i + 1, std::integral_constant<int, 2>{});
+          tile_step(i + 2, std::integral_constant<int, 3>{});
+        }
+      }
     }
 
     FA4K_STAMP(1);
     if constexpr (!CAUSAL) {
       pipe_drain(I1{}, I1{}, I1{});
+      if (nc_stage) {   // the V rows sit in SEL 1's b0, now b0 again: one more rotation makes it b2, where the next pass looks
+        const int bt = b0;
+        b0 = b1;
+        b1 = b2;
+        b2 = bt;
+      }
+      staged = nc_stage;
     } else {
       // ---- the 256 query rows level with the key tile: slot b0 (landed, published) and b1 (requested two tile steps ago) ----
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -600,16 +644,19 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkv4_kernel(BwdParams p) {
     FA4K_STAMP(3);
     // non-causal: the (out-of-range) fetches past the last tile are over before the ring is reused (causal: they were, at
     // the start of the diagonal phase -- what is in flight now are the NEXT pass's staged rows, which land outside the staging area)
-    if constexpr (!CAUSAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!CAUSAL) {
+      if (!staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     __syncthreads();  // every wave is done with the tile buffers: they become the staging area
-    if constexpr (CAUSAL) {
+    {
       if (staged) {   // something follows: its first two tiles and its first row constant are requested NOW -- the ring is free
                       // since the barrier above -- and land while dK / dV are written out
         const bool more_pass = pass + 1 < npass;
         const Work nw = more_pass ? wk : nwk_item;
         const int t0n = ktile_of(nw, more_pass ? pass + 1 : 0) * C::BK / C::BQ, n_mainn = ntiles - t0n - 2;
-        const int tn0 = n_mainn > 0 ? t0n + 2 : t0n, tn1 = n_mainn > 1 ? t0n + 3 : (n_mainn == 1 ? t0n : t0n + 1);
+        // (non-causal: the stream of a pass is tiles 0, 1, 2, ...)
+        const int tn0 = !CAUSAL ? 0 : (n_mainn > 0 ? t0n + 2 : t0n), tn1 = !CAUSAL ? 1 : (n_mainn > 1 ? t0n + 3 : (n_mainn == 1 ? t0n : t0n + 1));
         const __amdgpu_buffer_rsrc_t nrq = make_rsrc((const char*)p.q + nw.b * p.lq.sb + nw.h * p.lq.sh, view_bytes(Sq, q_rs, C::ROWB));
         const __amdgpu_buffer_rsrc_t nrdo = make_rsrc((const char*)p.dout + nw.b * p.ldo.sb + nw.h * p.ldo.sh, view_bytes(Sq, do_rs, C::ROWB));
         const __amdgpu_buffer_rsrc_t nrrc = make_rsrc((rc_lse ? p.lse : p.delta) + nw.b * p.lse_sb + nw.h * p.lse_sh, (unsigned)Sq * 4);
@@ -660,7 +707,7 @@ template <typename T, bool CAUSAL>
 static hipError_t launch4(const BwdParams& p, hipStream_t s) {
   using C = Dkv4Cfg;
   int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
-  if (CAUSAL) {   // persistent: one workgroup per CU walks the work list (a multiple of 8 keeps a workgroup on one XCD's items)
+  {   // persistent: one workgroup per CU walks the work list (a multiple of 8 keeps a workgroup on one XCD's items)
     static std::atomic<int> cus{0};   // CU count of the device first launched on (devices of one node are alike)
     int n = cus.load(std::memory_order_relaxed);
     if (n == 0) {
