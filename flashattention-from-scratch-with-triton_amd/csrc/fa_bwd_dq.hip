@@ -176,10 +176,15 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
     asm volatile("" ::: "memory");
   };
 
-  auto tile = [&](int t, auto masked_tag) __attribute__((always_inline)) {
+  // BUF: the tile's ring buffer as a compile-time constant (0 / 1), or -1 = t & 1 at run time.  With a constant buffer every
+  // LDS address of the tile is `per-lane offset + immediate`; with t & 1 hipcc rebuilds them with vector adds per read
+  // (D = 128: 3.6 vector instructions per MFMA where the maths needs 1.7, profiles/r04_pmc_summary_d128.txt).
+  auto tile = [&](int t, auto masked_tag, auto buf_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const FA_LDS char* kt = smem + (t & 1) * C::TILE_BYTES;
-    const FA_LDS char* vt = smem + (2 + (t & 1)) * C::TILE_BYTES;
+    constexpr int BUF = decltype(buf_tag)::value;
+    const int bsel = BUF >= 0 ? BUF : (t & 1);
+    const FA_LDS char* kt = smem + bsel * C::TILE_BYTES;
+    const FA_LDS char* vt = smem + (2 + bsel) * C::TILE_BYTES;
     const int s0 = t * C::BN;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -261,15 +266,26 @@ __global__ __launch_bounds__(256, OCC) void fa_bwd_dq_kernel(BwdParams p) {
   }
   dma_tile(0, 0);
   tile_sync();
+  using BR = std::integral_constant<int, -1>;
   int t = 0;
+  if constexpr (D == 128 && !DROP) {   // two tiles per trip, constant buffers (the first tile of a pass is tile 0: buffer 0)
+    for (; t + 2 <= nfull; t += 2) {
+      dma_tile(t + 1, 1);
+      tile(t, std::false_type{}, std::integral_constant<int, 0>{});
+      tile_sync();
+      if (t + 2 < ntiles) dma_tile(t + 2, 0);
+      tile(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+      tile_sync();
+    }
+  }
   for (; t < nfull; ++t) {
     if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-    tile(t, std::false_type{});
+    tile(t, std::false_type{}, BR{});
     tile_sync();
   }
   for (; t < ntiles; ++t) {
     if (t + 1 < ntiles) dma_tile(t + 1, (t + 1) & 1);
-    tile(t, std::true_type{});
+    tile(t, std::true_type{}, BR{});
     tile_sync();
   }
 
