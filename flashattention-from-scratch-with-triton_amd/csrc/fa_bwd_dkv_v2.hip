@@ -223,14 +223,49 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     };
 
     // ---- resident B operands: K^T and V^T of this wave's 32 keys ----
-    if (t_start < ntiles) fetch_tile(t_start, t_start & 1);
     vec8 kf[C::KS], vf[C::KS];
+    if constexpr (D == 128) {
+      // D = 128: the 2 x 8 KiB of this wave's K and V rows come through LDS -- LDS-DMA into the wave's own rows of the IDLE
+      // tile buffer (Q image: K, dO image: V; 16 coalesced 1-KiB pieces), read back as ds_read_b128 fragments -- instead of
+      // 16 per-lane fragment loads that touch 32 cache lines each and stall the wave ~250 cycles apiece wherever they are
+      // issued (fa_bwd_dq_v4.hip; profiles/r04_ab_lines.txt).  The first tile's requests follow, so a counted wait
+      // covers exactly them; the idle buffer is not written again before the barrier of the first commit.
+      const int ib = (t_start & 1) ^ 1;
+      int voff[8];
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      const int off = (kw0 + r) * kv_rs + (2 * ks + h) * 16;
-      kf[ks] = as_vec8<T>(buf_load16(rk, off));
-      if (FOLD && !p.q_prescaled) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
-      vf[ks] = as_vec8<T>(buf_load16(rv, off));
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + lane / C::CPR;   // row of the wave's 32-key block (4 rows per 1-KiB piece)
+        voff[i] = (kw0 + row) * kv_rs + swz_chunk<D>(row, lane % C::CPR) * 16 - 1024 * (i & 3);
+      }
+      const unsigned dstk = lds_addr_of(smem + ib * C::TILE_BYTES + wave * 32 * C::ROWB);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        dma_pieces<4>(rk, dstk + 4096 * g, voff + 4 * g, 0);
+        dma_pieces<4>(rv, dstk + C::DO_BASE + 4096 * g, voff + 4 * g, 0);
+      }
+      const bool first = t_start < ntiles;
+      if (first) fetch_tile(t_start, t_start & 1);
+      asm volatile("" ::: "memory");
+      // the first tile's 2 x DMA_PER_MAT pieces and its row-constant load are younger: leave them in flight
+      if (first) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * C::DMA_PER_MAT + 1) & 15) | (((2 * C::DMA_PER_MAT + 1) >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      asm volatile("" ::: "memory");
+      const FA_LDS char* kb = smem + ib * C::TILE_BYTES + wave * 32 * C::ROWB;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        kf[ks] = as_vec8<T>(lds_read16(kb + row_off[ks]));
+        if (FOLD && !p.q_prescaled) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
+        vf[ks] = as_vec8<T>(lds_read16(kb + C::DO_BASE + row_off[ks]));
+      }
+    } else {
+      if (t_start < ntiles) fetch_tile(t_start, t_start & 1);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int off = (kw0 + r) * kv_rs + (2 * ks + h) * 16;
+        kf[ks] = as_vec8<T>(buf_load16(rk, off));
+        if (FOLD && !p.q_prescaled) kf[ks] = scale_frag<T>(kf[ks], c2);  // K * softmax_scale * log2(e)
+        vf[ks] = as_vec8<T>(buf_load16(rv, off));
+      }
     }
     f32x16 dkacc[C::DB], dvacc[C::DB];
 #pragma unroll
