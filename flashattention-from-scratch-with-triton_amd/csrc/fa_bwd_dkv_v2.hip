@@ -73,18 +73,27 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  // D = 128 launches are persistent (launch2: one workgroup per CU walks items blockIdx.x, blockIdx.x + gridDim.x, ...):
+  // 2048 one-per-CU workgroups of ~0.1 ms each otherwise pay their start-up eight times over per CU
   const bool paired = CAUSAL && p.pair;
   const int per_bh = paired ? (p.n_tiles + 1) / 2 : p.n_tiles;
+  const int n_items = per_bh * p.B * p.H;
+#ifdef FA_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0, nblk_ = 0;
+#endif
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  if (item != (int)blockIdx.x) __syncthreads();   // the previous item staged dK / dV in the tile buffers
+  const int w = xcd_remap(item, n_items);
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
   const BatchHead ix = batch_head(bh, p.B, p.H, p.vl.cu_q != nullptr);
   const int b_ = ix.b, h_ = ix.h;
-  // variable-length launch (fa_kernels.h VarLen): this sequence's rows and lengths; surplus workgroups exit
+  // variable-length launch (fa_kernels.h VarLen): this sequence's rows and lengths; surplus items are skipped
   const SeqInfo si = seq_info(p.vl, b_, p.Sq, p.Sk);
   const int Sq = si.Sq, Sk = si.Sk;
   const int nk = (Sk + C::BK - 1) / C::BK;
-  if (idx >= (paired ? (nk + 1) / 2 : nk)) return;
+  if (idx >= (paired ? (nk + 1) / 2 : nk)) continue;
   const int npass = (paired && idx != nk - 1 - idx) ? 2 : 1;
 
   // Q, K, V, dO may be strided views with a contiguous head dim (fa_fwd.hip); dK and dV carry their own layouts
@@ -162,10 +171,6 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     __syncthreads();
   }
 
-#ifdef FA_STAMPS
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = 0, nblk_ = 0;
-#endif
   for (int pass = 0; pass < npass; ++pass) {
     const int kt_idx = paired ? (pass == 0 ? idx : nk - 1 - idx) : idx;  // low key tiles are the heavy ones
     const int k0_wg = kt_idx * C::BK;
@@ -661,6 +666,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     store_tile_rows<D, T>(dkacc, (FOLD && p.q_prescaled) ? kLn2 : p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
     store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
   }  // pass
+  }  // item
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {
     unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
@@ -677,7 +683,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
 template <int D, typename T, bool CAUSAL>
 static hipError_t launch2(const BwdParams& p, hipStream_t s) {
   using C = Dkv2Cfg<D>;
-  const int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  int grid = (CAUSAL && p.pair ? (p.n_tiles + 1) / 2 : p.n_tiles) * p.B * p.H;
+  if (D == 128) {   // one workgroup per CU at D = 128: persistent (the kernel's item loop); a multiple of 8 keeps a workgroup on one XCD's items
+    static std::atomic<int> cus{0};
+    int n = cus.load(std::memory_order_relaxed);
+    if (n == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+      n -= n % 8;
+      cus.store(n, std::memory_order_relaxed);
+    }
+    if (grid > n) grid = n;
+  }
   auto kern = fa_bwd_dkv2_kernel<D, T, CAUSAL>;
 #ifdef FA_STAMPS   // diagnostic builds only: extra LDS per workgroup forces one workgroup per CU (tools/stamps_dkv.py)
   static const int pad = getenv("FA_LDS_PAD") ? atoi(getenv("FA_LDS_PAD")) : 0;
