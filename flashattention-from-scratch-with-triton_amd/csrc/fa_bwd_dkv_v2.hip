@@ -82,8 +82,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = 0, nblk_ = 0;
 #endif
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-  if (item != (int)blockIdx.x) __syncthreads();   // the previous item staged dK / dV in the tile buffers
+  // (the D = 64 instances run the body once, visibly to the compiler: a loop they do not need costs them scalar registers)
+  constexpr bool PERSIST = D == 128;
+  int item = blockIdx.x;   // (launch2: the grid never exceeds the work list)
+  do {
+  if (PERSIST && item != (int)blockIdx.x) __syncthreads();   // the previous item staged dK / dV in the tile buffers
   const int w = xcd_remap(item, n_items);
   const int bh = w / per_bh;
   const int idx = w - bh * per_bh;
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void fa_bwd_dkv2_kernel(BwdPa
     store_tile_rows<D, T>(dkacc, (FOLD && p.q_prescaled) ? kLn2 : p.scale, stage, rdk, kw0 * dk_rs, lane, dk_rs);
     store_tile_rows<D, T>(dvacc, 1.0f, stage, rdv, kw0 * dv_rs, lane, dv_rs);
   }  // pass
-  }  // item
+  } while (PERSIST && (item += gridDim.x) < n_items);
 #ifdef FA_STAMPS
   if (p.dbg && lane == 0) {
     unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
