@@ -319,7 +319,8 @@ def test_dkv_family4_against_family3():
     for dtype in (BF16, F16):
         for causal in (False, True):
             for (B, H, Sq, Sk) in ((1, 2, 256, 256), (2, 3, 768, 768), (1, 2, 1024, 256), (1, 1, 128, 512), (2, 2, 1280, 1280),
-                                   (1, 2, 512, 1024), (1, 2, 500, 500), (4, 32, 512, 512)):
+                                   (1, 2, 512, 1024), (1, 2, 500, 500), (4, 32, 512, 512),
+                                   (6, 48, 768, 768)):   # > one item per persistent workgroup, causal and full
                 Q, K, V, dO = (x.cuda() for x in rand_inputs(B, H, Sq, Sk, 64, dtype, seed=Sq + Sk))
                 O, LSE = M.flash_attention_forward(Q, K, V, causal)
                 got = {}
@@ -359,7 +360,8 @@ def test_dq_family4_is_bit_identical_to_family3():
     for dtype in (BF16, F16):
         for causal in (False, True):
             for (B, H, Sq, Sk) in ((1, 2, 256, 256), (2, 3, 768, 768), (1, 2, 256, 1024), (1, 1, 200, 512), (2, 2, 1280, 1280),
-                                   (1, 2, 1024, 128), (1, 2, 500, 500), (4, 32, 512, 512)):
+                                   (1, 2, 1024, 128), (1, 2, 500, 500), (4, 32, 512, 512),
+                                   (6, 48, 768, 768)):   # > one item per persistent workgroup, causal and full
                 Q, K, V, dO = (x.cuda() for x in rand_inputs(B, H, Sq, Sk, 64, dtype, seed=Sq + Sk))
                 O, LSE = M.flash_attention_forward(Q, K, V, causal)
                 got = {}
