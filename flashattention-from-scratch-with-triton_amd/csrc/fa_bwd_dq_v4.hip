@@ -606,18 +606,27 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       };
       int kb[C::KS], tb[2][C::DB];
       int c = 0;
+#ifndef FA_STAMPS_ITER
+      FA4Q_STAMP(11);   // seg[11]: diagonal phase -- landing wait, barrier, next-stage descriptors
+#endif
       for (; c < wave; ++c) {   // key blocks below both diagonals
         tr_bases(tb, cbase(c));
         row_bases(kb, cbase(c + 1));
         block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tb, 0, kb, 0, no_hook);
         block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, no_hook);
       }
+#ifndef FA_STAMPS_ITER
+      FA4Q_STAMP(12);   // seg[12]: 2 w visits below both diagonals
+#endif
       // c = wave: row block 0's diagonal block, below row block 1's
       tr_bases(tb, cbase(c));
       row_bases(kb, cbase(c + 1));
       diag_start(0);
       block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_a);
       block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, hook_b);
+#ifndef FA_STAMPS_ITER
+      FA4Q_STAMP(13);   // seg[13]: the two visits of key block w (row block 0's diagonal)
+#endif
       // row block 1 alone: key blocks wave + 1 .. 6 - wave (an even number), then its diagonal block 7 - wave
       for (c = wave + 1; c < 7 - wave; c += 2) {
         tr_bases(tb, cbase(c));
@@ -627,6 +636,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
         row_bases(kb, cbase(c + 2));
         block_iter(I1{}, I1{}, I1{}, Yes{}, Yes{}, No{}, tb, 0, kb, 0, no_hook);
       }
+#ifndef FA_STAMPS_ITER
+      FA4Q_STAMP(14);   // seg[14]: 6 - 2 w solo visits of row block 1
+#endif
       tr_bases(tb, cbase(7 - wave));
       diag_start(1);
       block_iter(I0{}, I1{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_c);

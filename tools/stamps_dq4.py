@@ -54,7 +54,9 @@ for i, n in enumerate(names):
 for i, n in ((5, "prologue: ring primed (20 LDS-DMA pieces issued)"), (6, "prologue: Q / dO / O fetched, delta, scale, pinned"), (7, "prologue: first barrier (vmcnt(0))")):
     print("  %-70s %5.1f%% of wave lifetime  %8.0f cycles per pass" % (n, 100 * d[:, :, i].sum() / life, d[:, :, i].sum() / passes))
 if d[:, :, 9].sum() > 0 and d[:, :, 16].sum() == 0 and not DKV:
-    for i, n in ((9, "  of the prologue: loop bookkeeping (item decode, descriptors)"), (10, "  of the prologue: lane addresses, wait for the staged rows")):
+    for i, n in ((9, "  of the prologue: loop bookkeeping (item decode, descriptors)"), (10, "  of the prologue: lane addresses, wait for the staged rows"),
+                 (11, "  diagonal phase: landing wait, barrier, next-stage descriptors"), (12, "  diagonal phase: 2 w visits below both diagonals"),
+                 (13, "  diagonal phase: the two visits of key block w"), (14, "  diagonal phase: 6 - 2 w solo visits of row block 1")):
         print("  %-70s %5.1f%% of wave lifetime  %8.0f cycles per pass" % (n, 100 * d[:, :, i].sum() / life, d[:, :, i].sum() / passes))
 print("  unmasked tile: %.0f stamped cycles (96 MFMAs = 3072 matrix cycles)" % (d[:, :, 1].sum() / tiles))
 if d[:, :, 16].sum() > 0:   # a -DFA_STAMPS_ITER build (seg[16] = the commit)
