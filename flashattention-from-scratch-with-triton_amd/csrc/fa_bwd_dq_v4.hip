@@ -97,6 +97,12 @@ constexpr int dq4_cvt_tau(int j) { return j == 0 ? 13 : 14 + (j - 1) / 2; }
 #ifndef FA_DQ4_SPREAD_SLOT
 #define FA_DQ4_SPREAD_SLOT 2
 #endif
+// A/B hook (OFF): a barrier after every block visit of the diagonal phase (every wave makes nine) -- does lockstep matter?
+#ifdef FA_DQ4_DIAG_BARRIER
+#define FA_DQ4_DIAG_SYNC() __builtin_amdgcn_s_barrier()
+#else
+#define FA_DQ4_DIAG_SYNC() do {} while (0)
+#endif
 constexpr bool kDq4Spread = FA_DQ4_DMA_SPREAD != 0;   // (2: the four pairs in the MIDDLE of a tile step, iterations 2 and 4)
 constexpr bool kDq4Mid = FA_DQ4_DMA_SPREAD == 2;
 constexpr int kDq4SpreadSlot = FA_DQ4_SPREAD_SLOT;
@@ -612,8 +618,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       for (; c < wave; ++c) {   // key blocks below both diagonals
         tr_bases(tb, cbase(c));
         row_bases(kb, cbase(c + 1));
-        block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tb, 0, kb, 0, no_hook);
-        block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, no_hook);
+        block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, No{}, tb, 0, kb, 0, no_hook); FA_DQ4_DIAG_SYNC();
+        block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, no_hook); FA_DQ4_DIAG_SYNC();
       }
 #ifndef FA_STAMPS_ITER
       FA4Q_STAMP(12);   // seg[12]: 2 w visits below both diagonals
@@ -622,8 +628,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       tr_bases(tb, cbase(c));
       row_bases(kb, cbase(c + 1));
       diag_start(0);
-      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_a);
-      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, hook_b);
+      block_iter(I0{}, I0{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_a); FA_DQ4_DIAG_SYNC();
+      block_iter(I1{}, I1{}, I0{}, No{}, Yes{}, No{}, tb, 0, kb, 0, hook_b); FA_DQ4_DIAG_SYNC();
 #ifndef FA_STAMPS_ITER
       FA4Q_STAMP(13);   // seg[13]: the two visits of key block w (row block 0's diagonal)
 #endif
@@ -631,17 +637,17 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq4_kernel(BwdParams p) {
       for (c = wave + 1; c < 7 - wave; c += 2) {
         tr_bases(tb, cbase(c));
         row_bases(kb, cbase(c + 1));
-        block_iter(I0{}, I1{}, I1{}, Yes{}, Yes{}, No{}, tb, 0, kb, 0, no_hook);
+        block_iter(I0{}, I1{}, I1{}, Yes{}, Yes{}, No{}, tb, 0, kb, 0, no_hook); FA_DQ4_DIAG_SYNC();
         tr_bases(tb, cbase(c + 1));
         row_bases(kb, cbase(c + 2));
-        block_iter(I1{}, I1{}, I1{}, Yes{}, Yes{}, No{}, tb, 0, kb, 0, no_hook);
+        block_iter(I1{}, I1{}, I1{}, Yes{}, Yes{}, No{}, tb, 0, kb, 0, no_hook); FA_DQ4_DIAG_SYNC();
       }
 #ifndef FA_STAMPS_ITER
       FA4Q_STAMP(14);   // seg[14]: 6 - 2 w solo visits of row block 1
 #endif
       tr_bases(tb, cbase(7 - wave));
       diag_start(1);
-      block_iter(I0{}, I1{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_c);
+      block_iter(I0{}, I1{}, I1{}, Yes{}, No{}, Yes{}, tb, 0, kb, 0, hook_c); FA_DQ4_DIAG_SYNC();
       FA4Q_STAMP(2);
       pipe_drain(I0{}, I1{});
     }
